@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the over-particle transport path on MI355X.
+
+Workload (BASELINE.json: the metric is quoted on "problems/csp at 400x400,
+1e8 particles"): the csp deck at nx = ny = 400 with 1e8 source particles.  One
+bench "step" is one timestep of solve_transport_2d over every particle (the
+deck runs 10 of them).  With N GPUs the 1e8 particles are split into N
+contiguous id ranges (strong scaling), each rank tallies privately and the
+400x400 f64 tally is all-reduced (RCCL) at the end of every step.
+
+Timed region: W warm-up timesteps on a separate small particle set, then fresh
+injection, then exactly K timesteps (master_key 1..K) between barrier +
+torch.cuda.synchronize() pairs; MAX over ranks.  Inputs are resident in HBM
+before the timed region starts.
+
+One JSON line on rank 0 (see README "bench contract"), with
+  roofline     algorithmic bytes (SURVEY.md 8(d) model) per
+               launch / mean HIP-event duration of the history kernel
+  cpu_baseline the CPU oracle timed on this host's cores on a bounded sample of
+               the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (deck, nx, nparticles, deck iterations)
+    "csp": ("csp", 400, 100_000_000, 10),
+    "stream": ("stream", 400, 10_000_000, 1),
+    "scatter": ("scatter", 400, 100_000_000, 2),
+    "split": ("split", 800, 100_000_000, 1),
+}
+
+
+def algorithmic_bytes(histories, facets, collisions, census, same_tables):
+    """Global-memory bytes the algorithm must touch for one launch (SURVEY.md
+    8(d)): per history 152 B of particle state in+out, 8 B density and one pair
+    of cs lookups; per event 32 B of edges; per collision one more pair of
+    lookups; per facet 16 B tally RMW + 8 B density; per census 16 B tally RMW.
+    A pair of lookups is 15 probes x 16 B + 16 B of values per table = 512 B,
+    or 272 B when both tables are the same data and the search is shared."""
+    pair = 272 if same_tables else 512
+    events = facets + collisions + census
+    return (histories * (152 + 8 + pair) + events * 32 + collisions * pair +
+            facets * 24 + census * 16)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="csp", choices=sorted(WORKLOADS))
+    ap.add_argument("--nparticles", type=int, default=None,
+                    help="override the workload's total particle count")
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--variant", type=int, default=None, help="0 over-particle, 1 event-sorted")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target CPU work of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(deck, nx, its, target_seconds, tmp):
+    """Times the CPU oracle (tests/oracle_binding.py) on all host cores over a
+    bounded sample of the same workload: same deck, mesh and timestep count,
+    fewer particles (steps/s is intensive in N: BASELINE.md section 2)."""
+    import oracle_binding as ob
+    from neutral_amd import cs_table, decks, host
+
+    keys, values = cs_table.load()
+    cores = ob.lib().orc_num_threads()
+
+    def run(n):
+        path = decks.write_deck(deck, os.path.join(tmp, f"cpu_{n}.params"), nx=nx, ny=nx,
+                                nparticles=n, iterations=its)
+        prob = host.setup_problem(path, decks.ARCH_WIDTH, decks.ARCH_HEIGHT)
+        r = ob.OracleRun(prob, keys, values)
+        r.inject()
+        steps = 0
+        t0 = time.perf_counter()
+        for tt in range(1, its + 1):
+            steps += r.step(tt).particle_steps
+        return steps, time.perf_counter() - t0
+
+    n0 = 100_000
+    s0, t0 = run(n0)
+    n = int(min(max(n0, n0 * target_seconds / max(t0, 1e-3)), 20_000_000))
+    n = max(n0, (n // 1000) * 1000)
+    steps, secs = run(n)
+    return {"value": steps / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{deck} {nx}x{nx}, {n} particles, {its} timesteps, "
+                      f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not under a launcher: start one (child process; nothing here has touched the GPU)
+        port = os.environ.get("MASTER_PORT", "29517")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from neutral_amd import cs_table, decks, host
+    from neutral_amd import interface as iface
+    from neutral_amd.shard import StepTallyExchange, shard_range
+
+    iface.set_quiet(True)
+    deck, nx, ntotal, deck_its = WORKLOADS[args.workload]
+    nx = args.nx or nx
+    ntotal = args.nparticles or ntotal
+    K, W = args.steps, args.warmup
+    keys, values = cs_table.load()
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = decks.write_deck(deck, os.path.join(tmp, f"{deck}_r{rank}.params"), nx=nx,
+                                ny=nx, nparticles=ntotal, iterations=max(K, 1))
+        prob = host.setup_problem(path, decks.ARCH_WIDTH, decks.ARCH_HEIGHT)
+        first, count = shard_range(ntotal, rank, world)
+        sim = iface.Simulation(prob, keys, values, device=local_rank, shard=(first, count),
+                               variant=args.variant)
+        exchange = StepTallyExchange(sim.tally, world)
+        global_tally = sim.tally
+
+        def step(tt):
+            # kernels add into the per-step buffer; one all-reduce per step (N > 1)
+            sim.tally = exchange.begin_step()
+            r = sim.step(tt)
+            exchange.finish_step()
+            sim.tally = global_tally
+            return r
+
+        # ---- warm-up: W untimed timesteps, then restore the injected state ----
+        sim.inject()
+        for tt in range(1, W + 1):
+            step(tt)
+        sim.inject()
+        global_tally.zero_()
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        fence()
+        t0 = time.perf_counter()
+        results = [step(tt) for tt in range(1, K + 1)]
+        fence()
+        elapsed = time.perf_counter() - t0
+
+        stats = iface.last_step()
+        tot = torch.tensor([sum(r.facets for r in results), sum(r.collisions for r in results),
+                            sum(r.census for r in results), sum(r.nprocessed for r in results)],
+                           dtype=torch.float64, device=sim.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=sim.device)
+        if world > 1:
+            dist.all_reduce(tot)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        facets, collisions, census, histories = (int(v) for v in tot.tolist())
+        elapsed = float(tmax.item())
+        particle_steps = facets + collisions + census
+
+        if rank == 0:
+            # roofline of the dominant kernel (history kernel), this rank's launches
+            kernel_s = [r.kernel_ms * 1e-3 for r in results]
+            rbytes = [algorithmic_bytes(r.nprocessed, r.facets, r.collisions, r.census,
+                                        bool(stats.same_tables)) for r in results]
+            achieved = (sum(rbytes) / len(rbytes)) / (sum(kernel_s) / len(kernel_s)) / 1e9
+            out = {
+                "metric": "particle-steps/sec",
+                "value": particle_steps / elapsed,
+                "unit": "particle-steps/s",
+                "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": 1e3 * elapsed / K,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {"workload": f"problems/csp-style deck '{deck}' at nx=ny={nx}, "
+                                       f"{ntotal} particles, {K} timesteps"
+                           if deck == "csp" else
+                           f"deck '{deck}' at nx=ny={nx}, {ntotal} particles, {K} timesteps",
+                           "deck": deck, "nx": nx, "ny": nx, "nparticles": ntotal,
+                           "timesteps": K, "parallelism": f"particle-shard x{world}",
+                           "kernel_variant": int(stats.variant)},
+                "ns_per_particle_step": 1e9 * elapsed / particle_steps,
+                "histories_per_s": histories / elapsed,
+                "events": {"facets": facets, "collisions": collisions, "census": census,
+                           "histories": histories},
+                "global_tally": float(global_tally.sum().item()),
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "history_kernel",
+                             "kernel_ms_avg": 1e3 * sum(kernel_s) / len(kernel_s),
+                             "algorithmic_bytes_per_launch": sum(rbytes) / len(rbytes)},
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(deck, nx, K, args.cpu_seconds, tmp)
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            print(json.dumps(out), flush=True)
+        sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * neutral_hip.h -- C ABI of libneutral_hip.so, the MI355X (gfx950) kernel set
+ * for UoB-HPC/neutral's over-particle transport path.
+ *
+ * The library is a drop-in "kernel set" in the reference's sense (reference
+ * Makefile:2,83: KERNELS=<dir> selects one implementation of the three
+ * functions of neutral_interface.h).  Section 1 declares exactly those three
+ * symbols with the reference's signatures; section 2 declares the HBM flavour
+ * of the parent project's allocation hooks, through which the unchanged
+ * reference loader (neutral_data.c) places its buffers; section 3 holds the
+ * extensions that have no reference counterpart (device/stream selection,
+ * particle shards for multi-GPU, kernel variant, per-step statistics).
+ *
+ * Plain C types only: pointers marked [device] are HBM addresses (hipMalloc or
+ * any allocator handing out device memory, e.g. a torch CUDA tensor's
+ * data_ptr); all other pointers are host addresses.  All entry points are
+ * synchronous on return unless stated otherwise.  Fatal errors (HIP failures,
+ * allocation failures) print to stderr and exit(EXIT_FAILURE), the behaviour
+ * of the reference's TERMINATE sites (omp3/neutral.c:572).
+ */
+#ifndef NEUTRAL_HIP_H
+#define NEUTRAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data model ------------------------------------------------------------
+ * Layout-identical to the reference's types, so a reference translation unit
+ * compiled with -DSoA and this library agree on every struct they exchange. */
+
+/* = CrossSection, neutral_data.h:38-43 */
+typedef struct {
+  double* keys;   /* [device] nentries, strictly increasing, eV */
+  double* values; /* [device] nentries, barns */
+  int nentries;
+} NeutralHipCrossSection;
+
+/* = Particle under -DSoA, neutral_data.h:45-61: a host struct of device arrays */
+typedef struct {
+  double* x;                /* [device] */
+  double* y;                /* [device] */
+  double* omega_x;          /* [device] */
+  double* omega_y;          /* [device] */
+  double* energy;           /* [device] */
+  double* weight;           /* [device] */
+  double* dt_to_census;     /* [device] */
+  double* mfp_to_collision; /* [device] */
+  int* cellx;               /* [device] */
+  int* celly;               /* [device] */
+  int* dead;                /* [device] sticky death flag (omp3/neutral.c:91,245) */
+} NeutralHipParticle;
+
+/* ---- 1. the reference kernel interface (neutral_interface.h:11-36) ---------- */
+
+/* Replaces <KERNELS>/neutral.c:solve_transport_2d (omp3/neutral.c:19-40,
+ * neutral_interface.h:11-20).  Advances every live local particle by one
+ * timestep of length dt: re-samples its distance to collision with the
+ * Threefry2x64-20 stream (key = {particle id, master_key}, counter from 0),
+ * then processes collision / facet / census events until census or death,
+ * adding path-length heating into energy_deposition_tally with f64 atomics.
+ *   nx, ny                  local mesh extent without padding
+ *   global_nx, global_ny    global mesh extent (reflective outer boundary)
+ *   master_key              the timestep number tt (main.c:103)
+ *   pad, x_off, y_off       halo depth and rank offsets (0 in the reference)
+ *   ntotal_particles        global particle count: tallies are scaled by 1/N
+ *   nlocal_particles        [host, in] particles in this store; 0 -> prints
+ *                           "Out of particles" and returns
+ *   neighbours, edgedx, edgedy, reduce_array0..2   accepted, unused
+ *   particles               host struct of [device] arrays from inject_particles
+ *   density                 [device] ny*nx, row-major (celly*nx + cellx)
+ *   edgex, edgey            [device] nx+1 / ny+1 edge coordinates
+ *   cs_*_table              host structs of [device] arrays
+ *   energy_deposition_tally [device] ny*nx, accumulated (never zeroed here)
+ *   facet_events, collision_events  [host] incremented (omp3/neutral.c:202-203)
+ * Prints "Particles  <n processed>" like omp3/neutral.c:205 unless silenced. */
+void solve_transport_2d(
+    const int nx, const int ny, const int global_nx, const int global_ny,
+    const uint64_t master_key, const int pad, const int x_off, const int y_off,
+    const double dt, const int ntotal_particles, int* nlocal_particles,
+    const int* neighbours, NeutralHipParticle* particles, const double* density,
+    const double* edgex, const double* edgey, const double* edgedx,
+    const double* edgedy, NeutralHipCrossSection* cs_scatter_table,
+    NeutralHipCrossSection* cs_absorb_table, double* energy_deposition_tally,
+    uint64_t* reduce_array0, uint64_t* reduce_array1, uint64_t* reduce_array2,
+    uint64_t* facet_events, uint64_t* collision_events);
+
+/* Replaces inject_particles (omp3/neutral.c:560-630, neutral_interface.h:23-31).
+ * Allocates *particles (host struct + eleven [device] arrays of nparticles
+ * elements) and fills particles 0..nparticles-1: position uniform in the
+ * source box from stream (id, 0, ctr 0), direction from stream (id, 0, ctr 1),
+ * energy = initial_energy, weight 1, dt_to_census = dt, alive.  edgex/edgey are
+ * [device].  Returns the number of bytes allocated. */
+size_t inject_particles(const int nparticles, const int global_nx,
+                        const int local_nx, const int local_ny, const int pad,
+                        const double local_particle_left_off,
+                        const double local_particle_bottom_off,
+                        const double local_particle_width,
+                        const double local_particle_height, const int x_off,
+                        const int y_off, const double dt, const double* edgex,
+                        const double* edgey, const double initial_energy,
+                        NeutralHipParticle** particles);
+
+/* Replaces validate (omp3/neutral.c:520-557, neutral_interface.h:35-36): sums
+ * the [device] tally in index order on the host, prints
+ * "Final global_energy_tally %.15e", looks `params_filename` up in the tests
+ * file (default "problems/neutral.tests", neutral_data.h:33) and prints
+ * PASSED/FAILED at relative tolerance 1e-3 (neutral_data.h:27). */
+void validate(const int nx, const int ny, const char* params_filename,
+              const int rank, double* energy_tally);
+
+/* ---- 2. allocation hooks, HBM flavour ---------------------------------------
+ * The reference never allocates directly: neutral_data.c:97-105,168-169 and
+ * the parent project's mesh/shared-data set-up call these hooks, and the object
+ * linked in decides the memory space.  This flavour returns zero-filled HBM
+ * (hipMalloc) for the allocate_* family and host memory for allocate_host_*.
+ * Each allocate_* returns the bytes allocated. */
+size_t allocate_data(double** buf, size_t len);
+size_t allocate_float_data(float** buf, size_t len);
+size_t allocate_int_data(int** buf, size_t len);
+size_t allocate_uint64_data(uint64_t** buf, size_t len);
+void allocate_host_data(double** buf, size_t len);
+void allocate_host_int_data(int** buf, size_t len);
+void deallocate_data(double* buf);
+void deallocate_int_data(int* buf);
+void deallocate_uint64_data(uint64_t* buf);
+void deallocate_host_data(double* buf);
+/* send = 1 (RECV): *src [device] -> *dst [host]; send = 0 (SEND): host -> device
+ * (neutral_data.c:59-62 reads four edge scalars back with RECV) */
+void copy_buffer(const size_t len, double** src, double** dst, int send);
+void copy_int_buffer(const size_t len, int** src, int** dst, int send);
+/* uploads the host buffer *src into a new [device] buffer *dst, frees *src
+ * (neutral_data.c:168-169) */
+void move_host_buffer_to_device(const size_t len, double** src, double** dst);
+
+/* ---- 3. extensions (no reference counterpart) -------------------------------- */
+
+enum {
+  NEUTRAL_HIP_VARIANT_OVER_PARTICLE = 0, /* one lane owns a history (default) */
+  NEUTRAL_HIP_VARIANT_EVENT_SORTED = 1   /* lanes regrouped by next event */
+};
+
+typedef struct {
+  uint64_t nprocessed;  /* live particles advanced ("Particles  N") */
+  uint64_t facets;      /* facet events of the last step */
+  uint64_t collisions;  /* collision events of the last step */
+  uint64_t census;      /* histories of the last step that ended in a census event */
+  double kernel_ms;     /* HIP-event time of the step's kernels on their stream */
+  int same_tables;      /* 1 when both cs tables held identical data */
+  int variant;          /* kernel variant that ran */
+} NeutralHipStepStats;
+
+/* Number of visible devices (does not initialise a device context). */
+int neutral_hip_device_count(void);
+/* Selects the device for all following calls of this process. Returns 0 on success. */
+int neutral_hip_set_device(int device);
+/* Stream for all kernels and copies (a hipStream_t; NULL = the null stream). */
+void neutral_hip_set_stream(void* hip_stream);
+/* Particle shard: local particle i carries the global id pid_base + i as its
+ * RNG key, in inject_particles and solve_transport_2d alike.
+ * Default 0 = the reference's numbering. */
+void neutral_hip_set_pid_base(uint64_t pid_base);
+uint64_t neutral_hip_get_pid_base(void);
+/* Kernel variant for solve_transport_2d (NEUTRAL_HIP_VARIANT_*); also read once
+ * from the environment variable NEUTRAL_HIP_VARIANT.  Returns 0 on success. */
+int neutral_hip_set_variant(int variant);
+/* quiet != 0 suppresses the per-step "Particles  N" line. */
+void neutral_hip_set_quiet(int quiet);
+/* Path of the known-answer file used by validate(). */
+void neutral_hip_set_tests_file(const char* path);
+/* Statistics of the most recent solve_transport_2d call. */
+void neutral_hip_last_step(NeutralHipStepStats* stats);
+/* Resets particles 0..nparticles-1 of an existing store to their injected state
+ * (same arguments as inject_particles, no allocation). */
+void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
+                                    const int local_ny, const int pad,
+                                    const double local_particle_left_off,
+                                    const double local_particle_bottom_off,
+                                    const double local_particle_width,
+                                    const double local_particle_height,
+                                    const int x_off, const int y_off,
+                                    const double dt, const double* edgex,
+                                    const double* edgey,
+                                    const double initial_energy,
+                                    NeutralHipParticle* particles);
+/* Frees a store created by inject_particles. */
+void neutral_hip_free_particles(NeutralHipParticle* particles);
+/* Raw copies for callers without a HIP runtime of their own (ctypes, C). */
+void neutral_hip_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes);
+void neutral_hip_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes);
+void neutral_hip_memset(void* dst_device, int value, size_t bytes);
+void neutral_hip_synchronize(void);
+/* Unit probes of the device building blocks, for known-answer tests.  All
+ * pointers are HOST arrays; the library stages them through HBM.
+ *   threefry:  in3 = n rows {counter, pkey, master_key}; out2 = n rows of the
+ *              two Threefry2x64-20 words; rn2 = the two (0,1] doubles of
+ *              generate_random_numbers (omp3/neutral.c:632-652)
+ *   cs_lookup: microscopic_cs_for_energy (omp3/neutral.c:498-517) of `cs`
+ *              ([device] table) at n energies -> value and bracket index
+ *   distance_to_facet: in9 = n rows {x, y, omega_x, omega_y, speed, edgex[c],
+ *              edgex[c+1], edgey[c], edgey[c+1]} (omp3/neutral.c:423-471) */
+void neutral_hip_probe_threefry(const uint64_t* in3, uint64_t* out2, double* rn2, int n);
+void neutral_hip_probe_cs_lookup(const NeutralHipCrossSection* cs, const double* energy,
+                                 double* value, int* index, int n);
+void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, int* x_facet,
+                                         int n);
+/* Library/ABI version, bumped on any signature change. */
+int neutral_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,531 @@
+/*
+ * neutral_abi.hip -- the C ABI of libneutral_hip.so (include/neutral_hip.h):
+ * the three functions of the reference's neutral_interface.h, the HBM flavour
+ * of the allocation hooks, and the extension entry points.  Host code only;
+ * kernels live in neutral_kernels.hip.
+ */
+#include "../../include/neutral_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "neutral_kernels.h"
+
+extern "C" {
+/* host layer (neutral_amd/host/host.c), linked into this library */
+int get_key_value_parameter(const char* specifier, const char* filename, char* keys,
+                            double* values, int* nkeys);
+int within_tolerance(const double expected, const double result, const double tolerance);
+}
+
+#define NEUTRAL_ABI_VERSION 1
+#define NEUTRAL_MAX_KEYS 40
+#define NEUTRAL_MAX_STR_LEN 1024
+#define NEUTRAL_VALIDATE_TOLERANCE 1.0e-3 /* neutral_data.h:27 */
+
+#define HIP_CHECK(expr)                                                              \
+  do {                                                                               \
+    hipError_t err_ = (expr);                                                        \
+    if (err_ != hipSuccess) {                                                        \
+      fprintf(stderr, "libneutral_hip: %s failed: %s\n%s:%d\n", #expr,               \
+              hipGetErrorString(err_), __FILE__, __LINE__);                          \
+      exit(EXIT_FAILURE);                                                            \
+    }                                                                                \
+  } while (0)
+
+namespace {
+
+struct State {
+  hipStream_t stream = nullptr;
+  uint64_t pid_base = 0;
+  int variant = NEUTRAL_HIP_VARIANT_OVER_PARTICLE;
+  bool variant_from_env_done = false;
+  int quiet = 0;
+  char tests_file[NEUTRAL_MAX_STR_LEN] = "problems/neutral.tests"; /* neutral_data.h:33 */
+  NeutralHipStepStats last = {0, 0, 0, 0, 0.0, 0, 0};
+  /* per-device scratch, created on first use */
+  int scratch_device = -1;
+  neutral::StepCounters* d_counters = nullptr;
+  int* d_flag = nullptr;
+  hipEvent_t ev_start = nullptr;
+  hipEvent_t ev_stop = nullptr;
+};
+
+State g;
+
+void ensure_scratch() {
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (g.scratch_device == dev) {
+    return;
+  }
+  /* scratch of another device (if any) is abandoned: a process drives one GPU */
+  HIP_CHECK(hipMalloc((void**)&g.d_counters, sizeof(neutral::StepCounters)));
+  HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
+  HIP_CHECK(hipEventCreate(&g.ev_start));
+  HIP_CHECK(hipEventCreate(&g.ev_stop));
+  g.scratch_device = dev;
+}
+
+void read_variant_env() {
+  if (g.variant_from_env_done) {
+    return;
+  }
+  g.variant_from_env_done = true;
+  const char* v = getenv("NEUTRAL_HIP_VARIANT");
+  if (v && *v) {
+    const int iv = atoi(v);
+    if (iv == NEUTRAL_HIP_VARIANT_OVER_PARTICLE || iv == NEUTRAL_HIP_VARIANT_EVENT_SORTED) {
+      g.variant = iv;
+    } else {
+      fprintf(stderr, "libneutral_hip: ignoring NEUTRAL_HIP_VARIANT=%s\n", v);
+    }
+  }
+}
+
+void* device_zalloc(size_t bytes) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+  HIP_CHECK(hipMemsetAsync(p, 0, bytes ? bytes : 1, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  return p;
+}
+
+neutral::ParticleView view_of(const NeutralHipParticle* p) {
+  neutral::ParticleView v;
+  v.x = p->x;
+  v.y = p->y;
+  v.omega_x = p->omega_x;
+  v.omega_y = p->omega_y;
+  v.energy = p->energy;
+  v.weight = p->weight;
+  v.dt_to_census = p->dt_to_census;
+  v.mfp_to_collision = p->mfp_to_collision;
+  v.cellx = p->cellx;
+  v.celly = p->celly;
+  v.dead = p->dead;
+  return v;
+}
+
+void run_inject(const int nparticles, const int local_nx, const int local_ny, const int pad,
+                const double left_off, const double bottom_off, const double width,
+                const double height, const int x_off, const int y_off, const double dt,
+                const double* edgex, const double* edgey, const double initial_energy,
+                const NeutralHipParticle* particles) {
+  neutral::InjectArgs a;
+  a.nparticles = nparticles;
+  a.pid_base = g.pid_base;
+  a.local_nx = local_nx;
+  a.local_ny = local_ny;
+  a.pad = pad;
+  a.x_off = x_off;
+  a.y_off = y_off;
+  a.left_off = left_off;
+  a.bottom_off = bottom_off;
+  a.width = width;
+  a.height = height;
+  a.dt = dt;
+  a.initial_energy = initial_energy;
+  a.edgex = edgex;
+  a.edgey = edgey;
+  a.p = view_of(particles);
+  HIP_CHECK(neutral::launch_inject(a, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ---- 1. reference kernel interface ------------------------------------------ */
+
+void solve_transport_2d(const int nx, const int ny, const int global_nx, const int global_ny,
+                        const uint64_t master_key, const int pad, const int x_off,
+                        const int y_off, const double dt, const int ntotal_particles,
+                        int* nlocal_particles, const int* neighbours,
+                        NeutralHipParticle* particles, const double* density,
+                        const double* edgex, const double* edgey, const double* edgedx,
+                        const double* edgedy, NeutralHipCrossSection* cs_scatter_table,
+                        NeutralHipCrossSection* cs_absorb_table,
+                        double* energy_deposition_tally, uint64_t* reduce_array0,
+                        uint64_t* reduce_array1, uint64_t* reduce_array2,
+                        uint64_t* facet_events, uint64_t* collision_events) {
+  (void)neighbours;
+  (void)edgedx;
+  (void)edgedy;
+  (void)reduce_array0;
+  (void)reduce_array1;
+  (void)reduce_array2;
+
+  if (!(*nlocal_particles)) {
+    printf("Out of particles\n"); /* omp3/neutral.c:30-33 */
+    fflush(stdout);
+    return;
+  }
+  if (!particles || !particles->x || !particles->dead) {
+    fprintf(stderr, "libneutral_hip: solve_transport_2d needs a particle store made by "
+                    "this library's inject_particles (the dead[] array is required).\n");
+    exit(EXIT_FAILURE);
+  }
+  if (cs_scatter_table->nentries < 2 || cs_absorb_table->nentries < 2) {
+    fprintf(stderr, "libneutral_hip: cross-section tables need at least 2 entries.\n");
+    exit(EXIT_FAILURE);
+  }
+
+  read_variant_env();
+  ensure_scratch();
+
+  /* Identical tables (the shipped elastic_scatter.cs / capture.cs are) need one
+   * search per energy instead of two.  Decided from the data on every call, so
+   * a caller that rewrites a table in place is still served correctly. */
+  int same = 0;
+  if (cs_scatter_table->nentries == cs_absorb_table->nentries) {
+    if (cs_scatter_table->keys == cs_absorb_table->keys &&
+        cs_scatter_table->values == cs_absorb_table->values) {
+      same = 1;
+    } else {
+      int one = 1;
+      HIP_CHECK(hipMemcpyAsync(g.d_flag, &one, sizeof(int), hipMemcpyHostToDevice, g.stream));
+      HIP_CHECK(neutral::launch_tables_equal(cs_scatter_table->keys, cs_scatter_table->values,
+                                             cs_absorb_table->keys, cs_absorb_table->values,
+                                             cs_scatter_table->nentries, g.d_flag, g.stream));
+      HIP_CHECK(hipMemcpyAsync(&same, g.d_flag, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+      HIP_CHECK(hipStreamSynchronize(g.stream));
+    }
+  }
+
+  neutral::SolveArgs a;
+  a.nx = nx;
+  a.ny = ny;
+  a.global_nx = global_nx;
+  a.global_ny = global_ny;
+  a.master_key = master_key;
+  a.pad = pad;
+  a.x_off = x_off;
+  a.y_off = y_off;
+  a.dt = dt;
+  a.inv_ntotal_particles = 1.0 / (double)ntotal_particles; /* omp3/neutral.c:120 */
+  a.nparticles = *nlocal_particles;
+  a.pid_base = g.pid_base;
+  a.p = view_of(particles);
+  a.density = density;
+  a.edgex = edgex;
+  a.edgey = edgey;
+  a.scatter_keys = cs_scatter_table->keys;
+  a.scatter_values = cs_scatter_table->values;
+  a.scatter_n = cs_scatter_table->nentries;
+  a.absorb_keys = cs_absorb_table->keys;
+  a.absorb_values = cs_absorb_table->values;
+  a.absorb_n = cs_absorb_table->nentries;
+  a.same_tables = same;
+  a.tally = energy_deposition_tally;
+  a.counters = g.d_counters;
+
+  HIP_CHECK(hipMemsetAsync(g.d_counters, 0, sizeof(neutral::StepCounters), g.stream));
+  HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
+  HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
+  HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+
+  neutral::StepCounters h;
+  HIP_CHECK(hipMemcpyAsync(&h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  float ms = 0.0f;
+  HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
+
+  *facet_events += h.nfacets; /* omp3/neutral.c:202-203 */
+  *collision_events += h.ncollisions;
+
+  g.last.nprocessed = h.nprocessed;
+  g.last.facets = h.nfacets;
+  g.last.collisions = h.ncollisions;
+  g.last.census = h.ncensus;
+  g.last.kernel_ms = (double)ms;
+  g.last.same_tables = same;
+  g.last.variant = g.variant;
+
+  if (!g.quiet) {
+    printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */
+    fflush(stdout);
+  }
+}
+
+size_t inject_particles(const int nparticles, const int global_nx, const int local_nx,
+                        const int local_ny, const int pad,
+                        const double local_particle_left_off,
+                        const double local_particle_bottom_off,
+                        const double local_particle_width,
+                        const double local_particle_height, const int x_off, const int y_off,
+                        const double dt, const double* edgex, const double* edgey,
+                        const double initial_energy, NeutralHipParticle** particles) {
+  (void)global_nx;
+  NeutralHipParticle* p = (NeutralHipParticle*)malloc(sizeof(NeutralHipParticle));
+  if (!p) {
+    fprintf(stderr, "Could not allocate particle array.\n"); /* omp3/neutral.c:571-573 */
+    exit(EXIT_FAILURE);
+  }
+  const size_t n = (size_t)(nparticles > 0 ? nparticles : 0);
+  size_t allocation = 0;
+  double** f64[] = {&p->x,      &p->y,      &p->omega_x,      &p->omega_y,
+                    &p->energy, &p->weight, &p->dt_to_census, &p->mfp_to_collision};
+  for (double** f : f64) {
+    *f = (double*)device_zalloc(sizeof(double) * n);
+    allocation += sizeof(double) * n;
+  }
+  int** i32[] = {&p->cellx, &p->celly, &p->dead};
+  for (int** f : i32) {
+    *f = (int*)device_zalloc(sizeof(int) * n);
+    allocation += sizeof(int) * n;
+  }
+  *particles = p;
+
+  run_inject(nparticles, local_nx, local_ny, pad, local_particle_left_off,
+             local_particle_bottom_off, local_particle_width, local_particle_height, x_off,
+             y_off, dt, edgex, edgey, initial_energy, p);
+  return allocation;
+}
+
+void validate(const int nx, const int ny, const char* params_filename, const int rank,
+              double* energy_tally) {
+  const size_t ncells = (size_t)nx * (size_t)ny;
+  double* h_tally = (double*)malloc(sizeof(double) * (ncells ? ncells : 1));
+  if (!h_tally) {
+    fprintf(stderr, "Could not allocate the host tally.\n");
+    exit(EXIT_FAILURE);
+  }
+  HIP_CHECK(hipMemcpyAsync(h_tally, energy_tally, sizeof(double) * ncells,
+                           hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+
+  /* serial sum in index order, omp3/neutral.c:524-527 */
+  double global_energy_tally = 0.0;
+  for (size_t ii = 0; ii < ncells; ++ii) {
+    global_energy_tally += h_tally[ii];
+  }
+  free(h_tally);
+
+  if (rank != 0) {
+    return;
+  }
+  printf("\nFinal global_energy_tally %.15e\n", global_energy_tally);
+
+  int nresults = 0;
+  char* keys = (char*)malloc(sizeof(char) * NEUTRAL_MAX_KEYS * (NEUTRAL_MAX_STR_LEN + 1));
+  double* values = (double*)malloc(sizeof(double) * NEUTRAL_MAX_KEYS);
+  if (!keys || !values ||
+      !get_key_value_parameter(params_filename, g.tests_file, keys, values, &nresults) ||
+      nresults < 1) {
+    printf("Warning. Test entry was not found, could NOT validate.\n");
+    fflush(stdout);
+    free(keys);
+    free(values);
+    return;
+  }
+  printf("Expected %.12e, result was %.12e.\n", values[0], global_energy_tally);
+  if (within_tolerance(values[0], global_energy_tally, NEUTRAL_VALIDATE_TOLERANCE)) {
+    printf("PASSED validation.\n");
+  } else {
+    printf("FAILED validation.\n");
+  }
+  fflush(stdout);
+  free(keys);
+  free(values);
+}
+
+/* ---- 2. allocation hooks, HBM flavour ---------------------------------------- */
+
+size_t allocate_data(double** buf, size_t len) {
+  *buf = (double*)device_zalloc(sizeof(double) * len);
+  return sizeof(double) * len;
+}
+size_t allocate_float_data(float** buf, size_t len) {
+  *buf = (float*)device_zalloc(sizeof(float) * len);
+  return sizeof(float) * len;
+}
+size_t allocate_int_data(int** buf, size_t len) {
+  *buf = (int*)device_zalloc(sizeof(int) * len);
+  return sizeof(int) * len;
+}
+size_t allocate_uint64_data(uint64_t** buf, size_t len) {
+  *buf = (uint64_t*)device_zalloc(sizeof(uint64_t) * len);
+  return sizeof(uint64_t) * len;
+}
+void allocate_host_data(double** buf, size_t len) {
+  *buf = (double*)calloc(len ? len : 1, sizeof(double));
+  if (!*buf) {
+    fprintf(stderr, "Could not allocate host data.\n");
+    exit(EXIT_FAILURE);
+  }
+}
+void allocate_host_int_data(int** buf, size_t len) {
+  *buf = (int*)calloc(len ? len : 1, sizeof(int));
+  if (!*buf) {
+    fprintf(stderr, "Could not allocate host data.\n");
+    exit(EXIT_FAILURE);
+  }
+}
+void deallocate_data(double* buf) { HIP_CHECK(hipFree(buf)); }
+void deallocate_int_data(int* buf) { HIP_CHECK(hipFree(buf)); }
+void deallocate_uint64_data(uint64_t* buf) { HIP_CHECK(hipFree(buf)); }
+void deallocate_host_data(double* buf) { free(buf); }
+
+void copy_buffer(const size_t len, double** src, double** dst, int send) {
+  const hipMemcpyKind kind = send ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  HIP_CHECK(hipMemcpyAsync(*dst, *src, sizeof(double) * len, kind, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void copy_int_buffer(const size_t len, int** src, int** dst, int send) {
+  const hipMemcpyKind kind = send ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  HIP_CHECK(hipMemcpyAsync(*dst, *src, sizeof(int) * len, kind, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void move_host_buffer_to_device(const size_t len, double** src, double** dst) {
+  HIP_CHECK(hipMalloc((void**)dst, sizeof(double) * (len ? len : 1)));
+  HIP_CHECK(hipMemcpyAsync(*dst, *src, sizeof(double) * len, hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  free(*src);
+  *src = NULL;
+}
+
+/* ---- 3. extensions ------------------------------------------------------------ */
+
+int neutral_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    return 0;
+  }
+  return n;
+}
+
+int neutral_hip_set_device(int device) {
+  return hipSetDevice(device) == hipSuccess ? 0 : 1;
+}
+
+void neutral_hip_set_stream(void* hip_stream) { g.stream = (hipStream_t)hip_stream; }
+void neutral_hip_set_pid_base(uint64_t pid_base) { g.pid_base = pid_base; }
+uint64_t neutral_hip_get_pid_base(void) { return g.pid_base; }
+
+int neutral_hip_set_variant(int variant) {
+  if (variant != NEUTRAL_HIP_VARIANT_OVER_PARTICLE &&
+      variant != NEUTRAL_HIP_VARIANT_EVENT_SORTED) {
+    return 1;
+  }
+  g.variant = variant;
+  g.variant_from_env_done = true; /* an explicit choice overrides the environment */
+  return 0;
+}
+
+void neutral_hip_set_quiet(int quiet) { g.quiet = quiet; }
+
+void neutral_hip_set_tests_file(const char* path) {
+  strncpy(g.tests_file, path, NEUTRAL_MAX_STR_LEN - 1);
+  g.tests_file[NEUTRAL_MAX_STR_LEN - 1] = '\0';
+}
+
+void neutral_hip_last_step(NeutralHipStepStats* stats) { *stats = g.last; }
+
+void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
+                                    const int local_ny, const int pad,
+                                    const double local_particle_left_off,
+                                    const double local_particle_bottom_off,
+                                    const double local_particle_width,
+                                    const double local_particle_height, const int x_off,
+                                    const int y_off, const double dt, const double* edgex,
+                                    const double* edgey, const double initial_energy,
+                                    NeutralHipParticle* particles) {
+  run_inject(nparticles, local_nx, local_ny, pad, local_particle_left_off,
+             local_particle_bottom_off, local_particle_width, local_particle_height, x_off,
+             y_off, dt, edgex, edgey, initial_energy, particles);
+}
+
+void neutral_hip_free_particles(NeutralHipParticle* p) {
+  if (!p) {
+    return;
+  }
+  void* arrays[] = {p->x,      p->y,           p->omega_x,          p->omega_y, p->energy,
+                    p->weight, p->dt_to_census, p->mfp_to_collision, p->cellx,   p->celly,
+                    p->dead};
+  for (void* a : arrays) {
+    if (a) {
+      HIP_CHECK(hipFree(a));
+    }
+  }
+  free(p);
+}
+
+void neutral_hip_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes) {
+  HIP_CHECK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void neutral_hip_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes) {
+  HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+void neutral_hip_memset(void* dst_device, int value, size_t bytes) {
+  HIP_CHECK(hipMemsetAsync(dst_device, value, bytes, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+}
+
+}  // extern "C"
+
+/* probes: host arrays in, host arrays out; staging through HBM inside */
+namespace {
+template <typename T>
+T* stage_in(const T* host, size_t n) {
+  T* d = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d, sizeof(T) * (n ? n : 1)));
+  if (host && n) {
+    HIP_CHECK(hipMemcpyAsync(d, host, sizeof(T) * n, hipMemcpyHostToDevice, g.stream));
+  }
+  return d;
+}
+template <typename T>
+void stage_out(T* host, T* dev, size_t n) {
+  HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  HIP_CHECK(hipFree(dev));
+}
+}  // namespace
+
+extern "C" {
+
+void neutral_hip_probe_threefry(const uint64_t* in3, uint64_t* out2, double* rn2, int n) {
+  uint64_t* d_in = stage_in(in3, (size_t)3 * n);
+  uint64_t* d_out = stage_in((const uint64_t*)nullptr, (size_t)2 * n);
+  double* d_rn = stage_in((const double*)nullptr, (size_t)2 * n);
+  HIP_CHECK(neutral::launch_probe_threefry(d_in, d_out, d_rn, n, g.stream));
+  stage_out(out2, d_out, (size_t)2 * n);
+  stage_out(rn2, d_rn, (size_t)2 * n);
+  HIP_CHECK(hipFree(d_in));
+}
+
+void neutral_hip_probe_cs_lookup(const NeutralHipCrossSection* cs, const double* energy,
+                                 double* value, int* index, int n) {
+  double* d_e = stage_in(energy, (size_t)n);
+  double* d_v = stage_in((const double*)nullptr, (size_t)n);
+  int* d_i = stage_in((const int*)nullptr, (size_t)n);
+  HIP_CHECK(neutral::launch_probe_cs(cs->keys, cs->values, cs->nentries, d_e, d_v, d_i, n,
+                                     g.stream));
+  stage_out(value, d_v, (size_t)n);
+  stage_out(index, d_i, (size_t)n);
+  HIP_CHECK(hipFree(d_e));
+}
+
+void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, int* x_facet,
+                                         int n) {
+  double* d_in = stage_in(in9, (size_t)9 * n);
+  double* d_d = stage_in((const double*)nullptr, (size_t)n);
+  int* d_x = stage_in((const int*)nullptr, (size_t)n);
+  HIP_CHECK(neutral::launch_probe_facet(d_in, d_d, d_x, n, g.stream));
+  stage_out(distance, d_d, (size_t)n);
+  stage_out(x_facet, d_x, (size_t)n);
+  HIP_CHECK(hipFree(d_in));
+}
+
+void neutral_hip_synchronize(void) { HIP_CHECK(hipStreamSynchronize(g.stream)); }
+int neutral_hip_abi_version(void) { return NEUTRAL_ABI_VERSION; }
+
+}  // extern "C"

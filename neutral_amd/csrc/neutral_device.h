@@ -1,0 +1,169 @@
+/*
+ * neutral_device.h -- device-side building blocks of the MI355X (gfx950)
+ * over-particle transport path: Threefry2x64-20, the (0,1] double conversion,
+ * cross-section bracket search, distance-to-facet, the path-length heating
+ * estimator and the three event bodies.
+ *
+ * What is computed follows the reference's omp3 kernel set (the parity oracle,
+ * SURVEY.md section 2.3); each routine names the lines it answers to.  How it
+ * is computed is written for CDNA4: one lane per particle in 64-wide
+ * wavefronts, the whole history in VGPRs, every floating-point expression in
+ * the reference's association order (no fast-math, no reassociation) so that
+ * integer state (cells, event counts, RNG stream) matches the oracle exactly
+ * and tallies match to rounding.
+ */
+#ifndef NEUTRAL_AMD_DEVICE_H
+#define NEUTRAL_AMD_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace neutral {
+
+/* neutral_data.h:17-24 */
+constexpr double kEvToJ = 1.60217646e-19;
+constexpr double kAvogadros = 6.02214085774e23;
+constexpr double kBarns = 1.0e-28;
+constexpr double kParticleMass = 1.674927471213e-27;
+constexpr double kMassNo = 1.0e2;
+constexpr double kMolarMass = 1.0e-2;
+constexpr double kMinEnergyOfInterest = 1.0e0;
+constexpr double kOpenBoundCorrection = 1.0e-13;
+
+/* ---- Threefry2x64-20 (Random123/threefry.h:190-293, 20 rounds :179) ------ */
+
+template <unsigned N>
+__device__ __forceinline__ uint64_t rotl64(uint64_t v) {
+  return (v << N) | (v >> (64 - N));
+}
+
+#define NEUTRAL_TF_ROUND(R) \
+  a += b;                   \
+  b = rotl64<R>(b);         \
+  b ^= a;
+
+/* ctr = {counter, 0}, key = {pkey, master_key} (omp3/neutral.c:636-644). */
+__device__ __forceinline__ void threefry2x64_20(uint64_t c0, uint64_t k0,
+                                                uint64_t k1, uint64_t& r0,
+                                                uint64_t& r1) {
+  const uint64_t k2 = 0x1BD11BDAA9FC1A22ull ^ k0 ^ k1; /* threefry.h:170-171,203-209 */
+  uint64_t a = c0 + k0;
+  uint64_t b = k1; /* ctr.v[1] == 0 */
+  /* rotation schedule threefry.h:86-93 */
+  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
+  a += k1; b += k2 + 1;
+  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(32) NEUTRAL_TF_ROUND(24) NEUTRAL_TF_ROUND(21)
+  a += k2; b += k0 + 2;
+  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
+  a += k0; b += k1 + 3;
+  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(32) NEUTRAL_TF_ROUND(24) NEUTRAL_TF_ROUND(21)
+  a += k1; b += k2 + 4;
+  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
+  a += k2; b += k0 + 5;
+  r0 = a;
+  r1 = b;
+}
+#undef NEUTRAL_TF_ROUND
+
+/* u64 -> (0,1]: round-to-nearest conversion, then *2^-64 + 2^-65
+ * (omp3/neutral.c:646-651).  Both steps after the conversion are exact or
+ * singly rounded, so fusing them cannot change the result. */
+__device__ __forceinline__ double u64_to_unit(uint64_t r) {
+  constexpr double factor = 5.421010862427522170037264004349708557128906250e-20;      /* 2^-64 */
+  constexpr double half_factor = 2.710505431213761085018632002174854278564453125e-20; /* 2^-65 */
+  return (double)r * factor + half_factor;
+}
+
+/* omp3/neutral.c:632-652 */
+__device__ __forceinline__ void generate_random_numbers(uint64_t pkey,
+                                                        uint64_t master_key,
+                                                        uint64_t counter,
+                                                        double& rn0,
+                                                        double& rn1) {
+  uint64_t r0, r1;
+  threefry2x64_20(counter, pkey, master_key, r0, r1);
+  rn0 = u64_to_unit(r0);
+  rn1 = u64_to_unit(r1);
+}
+
+/* ---- cross-section tables -------------------------------------------------- */
+
+struct CsTable {
+  const double* keys;
+  const double* values;
+  int nentries;
+};
+
+/* Bracket search + linear interpolation (omp3/neutral.c:498-517).  The value
+ * depends only on the unique bracket keys[ind] <= E < keys[ind+1], so a plain
+ * bisection returns what the reference's stepping search returns.  Like the
+ * reference it requires keys[0] <= E < keys[n-1]; outside that range the
+ * reference loops forever or reads out of bounds, here the bracket clamps to
+ * the first/last interval (extrapolation) so a wave can never hang. */
+__device__ __forceinline__ int cs_bracket(const double* __restrict__ keys, int n,
+                                          double energy) {
+  int lo = 0;
+  int hi = n - 1; /* invariant: keys[lo] <= E < keys[hi] (after clamping) */
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (energy < keys[mid]) {
+      hi = mid;
+    } else {
+      lo = mid;
+    }
+  }
+  return lo;
+}
+
+__device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys,
+                                                 const double* __restrict__ values,
+                                                 int ind, double energy) {
+  const double k0 = keys[ind];
+  const double k1 = keys[ind + 1];
+  const double v0 = values[ind];
+  const double v1 = values[ind + 1];
+  return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
+}
+
+/* ---- geometry (omp3/neutral.c:423-471) ------------------------------------- */
+
+__device__ __forceinline__ void calc_distance_to_facet(
+    double x, double y, double omega_x, double omega_y, double speed,
+    double ex_lo, double ex_hi, double ey_lo, double ey_hi,
+    double& distance_to_facet, int& x_facet) {
+  const double u_x_inv = 1.0 / (omega_x * speed);
+  const double u_y_inv = 1.0 / (omega_y * speed);
+
+  /* the bound is open on the left/bottom: aim slightly past the edge */
+  const double ax = (omega_x >= 0.0) ? (ex_hi - x) : ((ex_lo - kOpenBoundCorrection) - x);
+  const double ay = (omega_y >= 0.0) ? (ey_hi - y) : ((ey_lo - kOpenBoundCorrection) - y);
+  const double dt_x = ax * u_x_inv;
+  const double dt_y = ay * u_y_inv;
+  x_facet = (dt_x < dt_y) ? 1 : 0;
+
+  distance_to_facet = x_facet ? (ax * speed) * u_x_inv : (ay * speed) * u_y_inv;
+}
+
+/* ---- heating estimator (omp3/neutral.c:474-495) ---------------------------- */
+
+__device__ __forceinline__ double calculate_energy_deposition(
+    double energy, double weight, double path_length, double number_density,
+    double microscopic_cs_absorb, double microscopic_cs_total) {
+  constexpr double average_exit_energy_absorb = 0.0;
+  const double absorption_heating =
+      (microscopic_cs_absorb / microscopic_cs_total) * average_exit_energy_absorb;
+  const double average_exit_energy_scatter =
+      energy * ((kMassNo * kMassNo + kMassNo + 1) / ((kMassNo + 1) * (kMassNo + 1)));
+  const double scattering_heating =
+      (1.0 - (microscopic_cs_absorb / microscopic_cs_total)) * average_exit_energy_scatter;
+  const double heating_response = (energy - scattering_heating - absorption_heating);
+  return weight * path_length * (microscopic_cs_total * kBarns) * heating_response *
+         number_density;
+}
+
+__device__ __forceinline__ double speed_of(double energy) {
+  return sqrt((2.0 * energy * kEvToJ) / kParticleMass); /* omp3/neutral.c:117,297 */
+}
+
+}  // namespace neutral
+#endif

@@ -1,0 +1,108 @@
+/*
+ * neutral_kernels.h -- launch-side view of the HIP kernels (host code of the
+ * C-ABI includes this; kernels are defined in neutral_kernels.hip).
+ */
+#ifndef NEUTRAL_AMD_KERNELS_H
+#define NEUTRAL_AMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace neutral {
+
+/* SoA particle store in HBM: the reference's -DSoA Particle
+ * (neutral_data.h:45-61).  One f64/i32 stream per field, lane i <-> particle
+ * base+i, so every prologue/epilogue access is a fully coalesced 512-B (f64) or
+ * 256-B (i32) wave transaction. */
+struct ParticleView {
+  double* x;
+  double* y;
+  double* omega_x;
+  double* omega_y;
+  double* energy;
+  double* weight;
+  double* dt_to_census;
+  double* mfp_to_collision;
+  int* cellx;
+  int* celly;
+  int* dead;
+};
+
+struct InjectArgs {
+  int nparticles;
+  uint64_t pid_base;
+  int local_nx;
+  int local_ny;
+  int pad;
+  int x_off;
+  int y_off;
+  double left_off;
+  double bottom_off;
+  double width;
+  double height;
+  double dt;
+  double initial_energy;
+  const double* edgex;
+  const double* edgey;
+  ParticleView p;
+};
+
+/* device-resident event counters of one solve step */
+struct StepCounters {
+  unsigned long long nprocessed;
+  unsigned long long nfacets;
+  unsigned long long ncollisions;
+  unsigned long long ncensus; /* histories that ended in a census event */
+};
+
+struct SolveArgs {
+  int nx;
+  int ny;
+  int global_nx;
+  int global_ny;
+  uint64_t master_key;
+  int pad;
+  int x_off;
+  int y_off;
+  double dt;
+  double inv_ntotal_particles;
+  int nparticles;
+  uint64_t pid_base;
+  ParticleView p;
+  const double* density;
+  const double* edgex;
+  const double* edgey;
+  const double* scatter_keys;
+  const double* scatter_values;
+  int scatter_n;
+  const double* absorb_keys;
+  const double* absorb_values;
+  int absorb_n;
+  int same_tables; /* both tables have identical contents: search once */
+  double* tally;
+  StepCounters* counters;
+};
+
+enum Variant {
+  kVariantOverParticle = 0, /* K1: one lane owns one history start to finish */
+  kVariantEventSorted = 1,  /* K2: lanes re-grouped by next event */
+};
+
+hipError_t launch_inject(const InjectArgs& a, hipStream_t stream);
+hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
+/* *d_flag (device int) = 1 when the two tables are element-wise identical */
+hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
+                               const double* vb, int n, int* d_flag, hipStream_t stream);
+
+
+/* unit probes of the device building blocks (all pointers [device]) */
+hipError_t launch_probe_threefry(const uint64_t* in, uint64_t* out, double* rn, int n,
+                                 hipStream_t stream);
+hipError_t launch_probe_cs(const double* keys, const double* values, int nentries,
+                           const double* energy, double* value, int* index, int n,
+                           hipStream_t stream);
+hipError_t launch_probe_facet(const double* in, double* dist, int* x_facet, int n,
+                              hipStream_t stream);
+
+}  // namespace neutral
+#endif

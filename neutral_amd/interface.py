@@ -1,0 +1,347 @@
+"""ctypes mirror of ``include/neutral_hip.h`` (libneutral_hip.so).
+
+The three functions keep the reference's names, argument order and meaning
+(``neutral_interface.h:11-36``); ``Simulation`` is a thin convenience that keeps
+the device buffers of one problem together, the way ``main.c`` keeps them in
+``Mesh``/``SharedData``/``NeutralData``.
+
+There is no CPU fallback: if the HIP library is missing, importing this module
+raises.  Device buffers are torch CUDA tensors (PyTorch is used for device
+memory, streams and ``torch.distributed`` only); particle arrays are allocated
+by the library's own ``inject_particles`` as in the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneutral_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} has not been built (run __graft_entry__.build() or "
+        "`make -C neutral_amd`); neutral_amd has no CPU fallback")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_u64p = C.POINTER(C.c_uint64)
+
+VARIANT_OVER_PARTICLE = 0
+VARIANT_EVENT_SORTED = 1
+
+F64_FIELDS = ("x", "y", "omega_x", "omega_y", "energy", "weight", "dt_to_census",
+              "mfp_to_collision")
+I32_FIELDS = ("cellx", "celly", "dead")
+
+
+class CrossSection(C.Structure):
+    """neutral_data.h:38-43"""
+    _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("nentries", C.c_int)]
+
+
+class Particle(C.Structure):
+    """neutral_data.h:45-61 (-DSoA): host struct of device arrays"""
+    _fields_ = [(n, C.c_void_p) for n in F64_FIELDS + I32_FIELDS]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("nprocessed", C.c_uint64), ("facets", C.c_uint64),
+                ("collisions", C.c_uint64), ("census", C.c_uint64),
+                ("kernel_ms", C.c_double),
+                ("same_tables", C.c_int), ("variant", C.c_int)]
+
+
+# every symbol include/neutral_hip.h declares
+ABI_SYMBOLS = (
+    "solve_transport_2d", "inject_particles", "validate",
+    "allocate_data", "allocate_float_data", "allocate_int_data", "allocate_uint64_data",
+    "allocate_host_data", "allocate_host_int_data", "deallocate_data",
+    "deallocate_int_data", "deallocate_uint64_data", "deallocate_host_data",
+    "copy_buffer", "copy_int_buffer", "move_host_buffer_to_device",
+    "neutral_hip_device_count", "neutral_hip_set_device", "neutral_hip_set_stream",
+    "neutral_hip_set_pid_base", "neutral_hip_get_pid_base", "neutral_hip_set_variant",
+    "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
+    "neutral_hip_reinject_particles", "neutral_hip_free_particles",
+    "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
+    "neutral_hip_synchronize", "neutral_hip_abi_version",
+    "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
+    "neutral_hip_probe_distance_to_facet",
+)
+
+_lib = C.CDLL(LIB_PATH)
+
+_lib.solve_transport_2d.restype = None
+_lib.solve_transport_2d.argtypes = [
+    C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
+    C.c_double, C.c_int, _ip, C.c_void_p, C.POINTER(Particle), C.c_void_p,
+    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(CrossSection),
+    C.POINTER(CrossSection), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    _u64p, _u64p]
+_lib.inject_particles.restype = C.c_size_t
+_lib.inject_particles.argtypes = [
+    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+    C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double,
+    C.POINTER(C.POINTER(Particle))]
+_lib.validate.restype = None
+_lib.validate.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+_lib.neutral_hip_device_count.restype = C.c_int
+_lib.neutral_hip_set_device.restype = C.c_int
+_lib.neutral_hip_set_device.argtypes = [C.c_int]
+_lib.neutral_hip_set_stream.argtypes = [C.c_void_p]
+_lib.neutral_hip_set_pid_base.argtypes = [C.c_uint64]
+_lib.neutral_hip_get_pid_base.restype = C.c_uint64
+_lib.neutral_hip_set_variant.restype = C.c_int
+_lib.neutral_hip_set_variant.argtypes = [C.c_int]
+_lib.neutral_hip_set_quiet.argtypes = [C.c_int]
+_lib.neutral_hip_set_tests_file.argtypes = [C.c_char_p]
+_lib.neutral_hip_last_step.argtypes = [C.POINTER(StepStats)]
+_lib.neutral_hip_reinject_particles.restype = None
+_lib.neutral_hip_reinject_particles.argtypes = [
+    C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+    C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(Particle)]
+_lib.neutral_hip_free_particles.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.neutral_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.neutral_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+_lib.neutral_hip_abi_version.restype = C.c_int
+_lib.neutral_hip_probe_threefry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+_lib.neutral_hip_probe_cs_lookup.argtypes = [C.POINTER(CrossSection), C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int]
+_lib.neutral_hip_probe_distance_to_facet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_int]
+
+
+def library() -> C.CDLL:
+    return _lib
+
+
+# ---- the three interface functions, reference names and argument order ---------
+
+def solve_transport_2d(nx, ny, global_nx, global_ny, master_key, pad, x_off, y_off, dt,
+                       ntotal_particles, nlocal_particles, neighbours, particles, density,
+                       edgex, edgey, edgedx, edgedy, cs_scatter_table, cs_absorb_table,
+                       energy_deposition_tally, reduce_array0, reduce_array1,
+                       reduce_array2, facet_events, collision_events):
+    """neutral_interface.h:11-20.  Pointer arguments are device addresses (ints)
+    or ctypes objects; `nlocal_particles`, `facet_events`, `collision_events` are
+    ctypes scalars passed by reference like the C int*/uint64_t*."""
+    _lib.solve_transport_2d(nx, ny, global_nx, global_ny, master_key, pad, x_off, y_off,
+                            dt, ntotal_particles, C.byref(nlocal_particles), neighbours,
+                            particles, density, edgex, edgey, edgedx, edgedy,
+                            C.byref(cs_scatter_table), C.byref(cs_absorb_table),
+                            energy_deposition_tally, reduce_array0, reduce_array1,
+                            reduce_array2, C.byref(facet_events), C.byref(collision_events))
+
+
+def inject_particles(nparticles, global_nx, local_nx, local_ny, pad,
+                     local_particle_left_off, local_particle_bottom_off,
+                     local_particle_width, local_particle_height, x_off, y_off, dt,
+                     edgex, edgey, initial_energy):
+    """neutral_interface.h:23-31.  Returns (particles, bytes_allocated), where
+    `particles` is the C `Particle*` the library allocated."""
+    pp = C.POINTER(Particle)()
+    nbytes = _lib.inject_particles(nparticles, global_nx, local_nx, local_ny, pad,
+                                   local_particle_left_off, local_particle_bottom_off,
+                                   local_particle_width, local_particle_height, x_off,
+                                   y_off, dt, edgex, edgey, initial_energy, C.byref(pp))
+    return pp, nbytes
+
+
+def validate(nx, ny, params_filename, rank, energy_tally):
+    """neutral_interface.h:35-36 (prints; returns nothing, like the reference)."""
+    _lib.validate(nx, ny, params_filename.encode(), rank, energy_tally)
+
+
+# ---- extensions -------------------------------------------------------------------
+
+def device_count() -> int:
+    return _lib.neutral_hip_device_count()
+
+
+def set_device(device: int) -> None:
+    if _lib.neutral_hip_set_device(device) != 0:
+        raise RuntimeError(f"hipSetDevice({device}) failed")
+
+
+def set_stream(stream_handle: int) -> None:
+    _lib.neutral_hip_set_stream(C.c_void_p(stream_handle))
+
+
+def set_pid_base(pid_base: int) -> None:
+    _lib.neutral_hip_set_pid_base(pid_base)
+
+
+def set_variant(variant: int) -> None:
+    if _lib.neutral_hip_set_variant(variant) != 0:
+        raise ValueError(f"unknown kernel variant {variant}")
+
+
+def set_quiet(quiet: bool) -> None:
+    _lib.neutral_hip_set_quiet(1 if quiet else 0)
+
+
+def set_tests_file(path: str) -> None:
+    _lib.neutral_hip_set_tests_file(path.encode())
+
+
+def last_step() -> StepStats:
+    s = StepStats()
+    _lib.neutral_hip_last_step(C.byref(s))
+    return s
+
+
+def to_host(device_ptr: int, n: int, dtype) -> np.ndarray:
+    out = np.empty(n, dtype=dtype)
+    if n:
+        _lib.neutral_hip_memcpy_d2h(out.ctypes.data, C.c_void_p(device_ptr), out.nbytes)
+    return out
+
+
+def probe_threefry(counter_pkey_mkey: np.ndarray):
+    """rows {counter, pkey, master_key} -> (words [n,2] uint64, rn [n,2] float64)"""
+    a = np.ascontiguousarray(counter_pkey_mkey, dtype=np.uint64).reshape(-1, 3)
+    n = a.shape[0]
+    words = np.zeros((n, 2), dtype=np.uint64)
+    rn = np.zeros((n, 2), dtype=np.float64)
+    _lib.neutral_hip_probe_threefry(a.ctypes.data, words.ctypes.data, rn.ctypes.data, n)
+    return words, rn
+
+
+def probe_cs_lookup(cs: CrossSection, energies: np.ndarray):
+    e = np.ascontiguousarray(energies, dtype=np.float64)
+    value = np.zeros(e.size, dtype=np.float64)
+    index = np.zeros(e.size, dtype=np.int32)
+    _lib.neutral_hip_probe_cs_lookup(C.byref(cs), e.ctypes.data, value.ctypes.data,
+                                     index.ctypes.data, e.size)
+    return value, index
+
+
+def probe_distance_to_facet(rows: np.ndarray):
+    """rows {x, y, omega_x, omega_y, speed, ex_lo, ex_hi, ey_lo, ey_hi}"""
+    a = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 9)
+    dist = np.zeros(a.shape[0], dtype=np.float64)
+    xf = np.zeros(a.shape[0], dtype=np.int32)
+    _lib.neutral_hip_probe_distance_to_facet(a.ctypes.data, dist.ctypes.data,
+                                             xf.ctypes.data, a.shape[0])
+    return dist, xf
+
+
+@dataclass
+class StepResult:
+    nprocessed: int
+    facets: int
+    collisions: int
+    kernel_ms: float
+    census: int = 0
+
+    @property
+    def particle_steps(self) -> int:
+        """trips of the event loop (omp3/neutral.c:134): facets + collisions + census"""
+        return self.facets + self.collisions + self.census
+
+
+class Simulation:
+    """Device-side state of one problem (or one particle shard of it).
+
+    `shard = (first, count)` makes this process own global particles
+    [first, first+count); the RNG key of local particle i is first + i, so any
+    partition reproduces the single-GPU histories.
+    """
+
+    def __init__(self, problem, cs_keys, cs_values, device: int = 0, shard=None,
+                 cs_absorb=None, variant: Optional[int] = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("neutral_amd.interface.Simulation needs a GPU")
+        self.torch = torch
+        self.p = problem
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        set_device(device)
+        set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if variant is not None:
+            set_variant(variant)
+        first, count = shard if shard is not None else (0, problem.nparticles)
+        self.pid_base, self.n = int(first), int(count)
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+        self.edgex, self.edgey = dev(problem.edgex), dev(problem.edgey)
+        self.edgedx, self.edgedy = dev(problem.edgedx), dev(problem.edgedy)
+        self.density = dev(problem.density)
+        self.tally = torch.zeros(problem.nx * problem.ny, dtype=torch.float64,
+                                 device=self.device)
+        self._sk, self._sv = dev(cs_keys), dev(cs_values)
+        if cs_absorb is None:
+            # two separate device copies, as neutral_data.c:176-177 reads both files
+            self._ak, self._av = dev(cs_keys), dev(cs_values)
+        else:
+            self._ak, self._av = dev(cs_absorb[0]), dev(cs_absorb[1])
+        self.cs_scatter = CrossSection(self._sk.data_ptr(), self._sv.data_ptr(), len(cs_keys))
+        self.cs_absorb = CrossSection(self._ak.data_ptr(), self._av.data_ptr(),
+                                      self._ak.numel())
+        self.particles = None
+        self.nlocal = C.c_int(self.n)
+        self.bytes_allocated = 0
+
+    def _inject_args(self):
+        p = self.p
+        return (p.nx, p.ny, p.pad, p.local_particle_left_off, p.local_particle_bottom_off,
+                p.local_particle_width, p.local_particle_height, p.x_off, p.y_off, p.dt,
+                self.edgex.data_ptr(), self.edgey.data_ptr(), p.initial_energy)
+
+    def inject(self):
+        """inject_particles on first use, a state reset (no allocation) afterwards."""
+        set_pid_base(self.pid_base)
+        if self.particles is None:
+            p = self.p
+            self.particles, self.bytes_allocated = inject_particles(
+                self.n, p.nx, *self._inject_args())
+        else:
+            _lib.neutral_hip_reinject_particles(self.n, *self._inject_args(), self.particles)
+
+    def step(self, master_key: int) -> StepResult:
+        p = self.p
+        set_pid_base(self.pid_base)
+        facets, collisions = C.c_uint64(0), C.c_uint64(0)
+        solve_transport_2d(
+            p.nx - 2 * p.pad, p.ny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, p.x_off,
+            p.y_off, p.dt, p.nparticles, self.nlocal, None, self.particles,
+            self.density.data_ptr(), self.edgex.data_ptr(), self.edgey.data_ptr(),
+            self.edgedx.data_ptr(), self.edgedy.data_ptr(), self.cs_scatter,
+            self.cs_absorb, self.tally.data_ptr(), None, None, None, facets, collisions)
+        s = last_step()
+        return StepResult(int(s.nprocessed), facets.value, collisions.value, s.kernel_ms,
+                          int(s.census))
+
+    def particle_arrays(self):
+        """Host copies of the SoA particle store."""
+        pc = self.particles.contents
+        out = {}
+        for f in F64_FIELDS:
+            out[f] = to_host(getattr(pc, f), self.n, np.float64)
+        for f in I32_FIELDS:
+            out[f] = to_host(getattr(pc, f), self.n, np.int32)
+        return out
+
+    def tally_host(self) -> np.ndarray:
+        return self.tally.cpu().numpy()
+
+    def zero_tally(self):
+        self.tally.zero_()
+
+    def validate(self, params_filename: Optional[str] = None):
+        validate(self.p.nx, self.p.ny, params_filename or self.p.deck, 0,
+                 self.tally.data_ptr())
+
+    def close(self):
+        if self.particles is not None:
+            _lib.neutral_hip_free_particles(self.particles)
+            self.particles = None

@@ -205,6 +205,11 @@ static inline void tally_add(double* tally, int nx, int x_off, int y_off,
   tally[celly * nx + cellx] += energy_deposition * inv_ntotal_particles;
 }
 
+/* census events of the most recent orc_solve_transport_2d call (bookkeeping for
+ * the particle-steps metric; the reference does not count them) */
+static uint64_t g_last_census = 0;
+uint64_t orc_last_census(void) { return g_last_census; }
+
 /* omp3/neutral.c:19-206 */
 uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
                                 uint64_t master_key, int pad, int x_off,
@@ -226,11 +231,12 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
   uint64_t nfacets = 0;
   uint64_t ncollisions = 0;
   uint64_t nprocessed = 0;
+  uint64_t ncensus = 0;
 
   /* omp3/neutral.c:64-78 is a hand-written static block partition; schedule
    * (static) over the same index range assigns the same contiguous blocks. */
 #pragma omp parallel for schedule(static) \
-    reduction(+ : nfacets, ncollisions, nprocessed)
+    reduction(+ : nfacets, ncollisions, nprocessed, ncensus)
   for (int pid = 0; pid < nparticles_to_process; ++pid) {
     if (p->dead[pid]) {
       continue; /* omp3/neutral.c:91-93 */
@@ -429,6 +435,7 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
         tally_add(energy_deposition_tally, nx, x_off, y_off, pcellx, pcelly,
                   inv_ntotal_particles, energy_deposition);
         dt_to_census = 0.0;
+        ncensus++;
         break;
       }
     }
@@ -449,6 +456,7 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
   /* omp3/neutral.c:202-205 */
   *facets += nfacets;
   *collisions += ncollisions;
+  g_last_census = ncensus;
   return nprocessed;
 }
 

@@ -114,6 +114,10 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
                                 double* energy_deposition_tally,
                                 uint64_t* facets, uint64_t* collisions);
 
+/* histories of the most recent orc_solve_transport_2d call that ended in a
+ * census event (not counted by the reference; needed for particle-steps) */
+uint64_t orc_last_census(void);
+
 /* omp3/neutral.c:524-527: serial sum of the tally mesh */
 double orc_sum_tally(int nx, int ny, const double* energy_deposition_tally);
 
