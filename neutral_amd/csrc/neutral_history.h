@@ -1,0 +1,261 @@
+/*
+ * neutral_history.h -- one particle history held in registers, and the event
+ * bodies that advance it.  Shared by every history kernel variant so that all
+ * of them execute the same floating-point operations in the same order:
+ * variants differ only in WHICH lane runs WHICH event WHEN, never in what an
+ * event computes.
+ *
+ * Mapping to the reference (omp3/neutral.c):
+ *   load/store        the Particle fields (neutral_data.h:45-61)
+ *   prologue          handle_particles :103-131
+ *   decide            the loop head :134-150,170 (which event is next)
+ *   collide           collision_event :209-300
+ *   cross_facet       facet_event :303-380
+ *   census            census_event :383-405
+ */
+#ifndef NEUTRAL_AMD_HISTORY_H
+#define NEUTRAL_AMD_HISTORY_H
+
+#include "neutral_device.h"
+#include "neutral_kernels.h"
+
+namespace neutral {
+
+enum Event : int {
+  kEvEnd = 0,       /* dt_to_census <= 0: the while loop at :134 exits */
+  kEvFacet = 1,
+  kEvCollision = 2,
+  kEvCensus = 3,
+};
+
+struct History {
+  /* particle state */
+  double x, y, omega_x, omega_y, energy, weight, dt_to_census, mfp_to_collision;
+  int cellx, celly, dead;
+  /* locals of handle_particles that live across events */
+  double local_density, micro_s, micro_a, number_density, macro_s, macro_a, speed;
+  double energy_deposition;
+  uint64_t pkey;
+  unsigned counter;
+  /* the decision taken at the loop head */
+  double cell_mfp, distance;
+  int x_facet;
+  int ev;
+};
+
+/* omp3/neutral.c:408-420 */
+__device__ __forceinline__ void update_tallies(const SolveArgs& a, int pcellx, int pcelly,
+                                               double energy_deposition) {
+  const int cellx = pcellx - a.x_off;
+  const int celly = pcelly - a.y_off;
+#if defined(NEUTRAL_EXP_NO_TALLY)
+  /* timing experiment only: keep the value alive, drop the memory operation */
+  if (energy_deposition == 1.2345e300) a.tally[celly * a.nx + cellx] = energy_deposition;
+#else
+  unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], energy_deposition * a.inv_ntotal_particles);
+#endif
+}
+
+/* both microscopic cross sections for one energy */
+template <bool kSameTables>
+__device__ __forceinline__ void lookup_cs(const SolveArgs& a, double energy, double& micro_scatter,
+                                          double& micro_absorb) {
+  const int is = cs_bracket(a.scatter_keys, a.scatter_n, energy);
+  micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
+  if (kSameTables) {
+    micro_absorb = micro_scatter;
+  } else {
+    const int ia = cs_bracket(a.absorb_keys, a.absorb_n, energy);
+    micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
+  }
+}
+
+__device__ __forceinline__ void macroscopic_from_density(History& h) {
+  /* omp3/neutral.c:112-116, :289-291, :375-377 */
+  h.number_density = (h.local_density * kAvogadros / kMolarMass);
+  h.macro_s = h.number_density * h.micro_s * kBarns;
+  h.macro_a = h.number_density * h.micro_a * kBarns;
+}
+
+__device__ __forceinline__ void load_particle(History& h, const SolveArgs& a, int pid) {
+  h.x = a.p.x[pid];
+  h.y = a.p.y[pid];
+  h.omega_x = a.p.omega_x[pid];
+  h.omega_y = a.p.omega_y[pid];
+  h.energy = a.p.energy[pid];
+  h.weight = a.p.weight[pid];
+  h.cellx = a.p.cellx[pid];
+  h.celly = a.p.celly[pid];
+  h.dead = 0;
+  h.pkey = a.pid_base + (uint64_t)pid; /* omp3/neutral.c:89 */
+}
+
+__device__ __forceinline__ void store_particle(const History& h, const SolveArgs& a, int pid) {
+  a.p.x[pid] = h.x;
+  a.p.y[pid] = h.y;
+  a.p.omega_x[pid] = h.omega_x;
+  a.p.omega_y[pid] = h.omega_y;
+  a.p.energy[pid] = h.energy;
+  a.p.weight[pid] = h.weight;
+  a.p.dt_to_census[pid] = h.dt_to_census;
+  a.p.mfp_to_collision[pid] = h.mfp_to_collision;
+  a.p.cellx[pid] = h.cellx;
+  a.p.celly[pid] = h.celly;
+  a.p.dead[pid] = h.dead;
+}
+
+/* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */
+template <bool kSameTables>
+__device__ __forceinline__ void prologue(History& h, const SolveArgs& a) {
+  h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
+                              (h.cellx - a.x_off + a.pad)];
+  lookup_cs<kSameTables>(a, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_density(h);
+  h.speed = speed_of(h.energy);
+  h.energy_deposition = 0.0;
+  h.counter = 0;
+  h.dt_to_census = a.dt;
+  double rn0, rn1;
+  generate_random_numbers(h.pkey, a.master_key, h.counter++, rn0, rn1);
+  h.mfp_to_collision = -log(rn0) / h.macro_s;
+}
+
+/* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
+__device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
+  if (!(h.dt_to_census > 0.0)) {
+    h.ev = kEvEnd;
+    return;
+  }
+  h.cell_mfp = 1.0 / (h.macro_s + h.macro_a);
+  const int ex = h.cellx - a.x_off + a.pad;
+  const int ey = h.celly - a.y_off + a.pad;
+  double distance_to_facet;
+  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, a.edgex[ex], a.edgex[ex + 1],
+                         a.edgey[ey], a.edgey[ey + 1], distance_to_facet, h.x_facet);
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  if (distance_to_collision < distance_to_facet && distance_to_collision < distance_to_census) {
+    h.ev = kEvCollision;
+    h.distance = distance_to_collision;
+  } else if (distance_to_facet < distance_to_census) {
+    h.ev = kEvFacet;
+    h.distance = distance_to_facet;
+  } else {
+    h.ev = kEvCensus;
+    h.distance = distance_to_census;
+  }
+}
+
+/* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
+template <bool kSameTables>
+__device__ __forceinline__ bool collide(History& h, const SolveArgs& a) {
+  const double distance_to_collision = h.distance;
+  h.energy_deposition +=
+      calculate_energy_deposition(h.energy, h.weight, distance_to_collision, h.number_density,
+                                  h.micro_a, h.micro_s + h.micro_a);
+  h.x += distance_to_collision * h.omega_x;
+  h.y += distance_to_collision * h.omega_y;
+
+  const double p_absorb = h.macro_a / (h.macro_s + h.macro_a);
+  double rc0, rc1;
+  generate_random_numbers(h.pkey, a.master_key, h.counter++, rc0, rc1);
+
+  if (rc0 < p_absorb) {
+    /* absorption: the weight drops; below 1 eV the history ends here */
+    h.weight *= (1.0 - p_absorb);
+    if (h.energy < kMinEnergyOfInterest) {
+      h.dead = 1;
+      update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+      h.energy_deposition = 0.0;
+      return true;
+    }
+  } else {
+    /* elastic scatter off a nucleus of mass number A */
+    const double mu_cm = 1.0 - 2.0 * rc1;
+    const double e_new = h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0) /
+                         ((kMassNo + 1.0) * (kMassNo + 1.0));
+    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / h.energy) -
+                                    (kMassNo - 1.0) * sqrt(h.energy / e_new));
+    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
+    const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
+    h.omega_x = omega_x_new;
+    h.omega_y = omega_y_new;
+    h.energy = e_new;
+  }
+
+  lookup_cs<kSameTables>(a, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_density(h);
+
+  double rn0, rn1;
+  generate_random_numbers(h.pkey, a.master_key, h.counter++, rn0, rn1);
+  h.mfp_to_collision = -log(rn0) / h.macro_s;
+  h.dt_to_census -= distance_to_collision / h.speed;
+  h.speed = speed_of(h.energy);
+  return false;
+}
+
+/* facet_event, omp3/neutral.c:303-380 */
+__device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a) {
+  const double distance_to_facet = h.distance;
+  h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
+  h.dt_to_census -= (distance_to_facet / h.speed);
+  h.energy_deposition +=
+      calculate_energy_deposition(h.energy, h.weight, distance_to_facet, h.number_density,
+                                  h.micro_a, h.micro_s + h.micro_a);
+  update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+  h.energy_deposition = 0.0;
+
+  h.x += distance_to_facet * h.omega_x;
+  h.y += distance_to_facet * h.omega_y;
+
+  /* step to the neighbour cell, or reflect at the outer boundary */
+  if (h.x_facet) {
+    if (h.omega_x > 0.0) {
+      if (h.cellx >= (a.global_nx - 1)) {
+        h.omega_x = -h.omega_x;
+      } else {
+        h.cellx++;
+      }
+    } else if (h.omega_x < 0.0) {
+      if (h.cellx <= 0) {
+        h.omega_x = -h.omega_x;
+      } else {
+        h.cellx--;
+      }
+    }
+  } else {
+    if (h.omega_y > 0.0) {
+      if (h.celly >= (a.global_ny - 1)) {
+        h.omega_y = -h.omega_y;
+      } else {
+        h.celly++;
+      }
+    } else if (h.omega_y < 0.0) {
+      if (h.celly <= 0) {
+        h.omega_y = -h.omega_y;
+      } else {
+        h.celly--;
+      }
+    }
+  }
+
+  h.local_density = a.density[(h.celly - a.y_off) * a.nx + (h.cellx - a.x_off)];
+  macroscopic_from_density(h);
+}
+
+/* census_event, omp3/neutral.c:383-405 */
+__device__ __forceinline__ void census(History& h, const SolveArgs& a) {
+  const double distance_to_census = h.distance;
+  h.x += distance_to_census * h.omega_x;
+  h.y += distance_to_census * h.omega_y;
+  h.mfp_to_collision -= (distance_to_census / h.cell_mfp);
+  h.energy_deposition +=
+      calculate_energy_deposition(h.energy, h.weight, distance_to_census, h.number_density,
+                                  h.micro_a, h.micro_s + h.micro_a);
+  update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+  h.dt_to_census = 0.0;
+}
+
+}  // namespace neutral
+#endif

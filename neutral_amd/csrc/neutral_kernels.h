@@ -53,6 +53,8 @@ struct StepCounters {
   unsigned long long nfacets;
   unsigned long long ncollisions;
   unsigned long long ncensus; /* histories that ended in a census event */
+  unsigned int queue_head;    /* K2: next unclaimed particle index */
+  unsigned int pad_;
 };
 
 struct SolveArgs {

@@ -4,6 +4,7 @@
  *
  *   K0 inject_kernel       initial particle state        (omp3/neutral.c:560-630)
  *   K1 history_kernel      one lane = one history         (omp3/neutral.c:43-206)
+ *   K2 history_regroup_kernel  persistent waves, lanes regrouped by next event
  *   tables_equal_kernel    are the two cs tables the same data?
  *
  * Execution model: one work-item per particle, 64-wide wavefronts, 256-thread
@@ -20,10 +21,20 @@
 #include "neutral_kernels.h"
 
 #include "neutral_device.h"
+#include "neutral_history.h"
 
 namespace neutral {
 
 constexpr int kBlock = 256;
+
+/* minimum resident waves per SIMD the register allocator must leave room for
+ * (second __launch_bounds__ argument): 4 <=> at most 128 VGPRs */
+#ifndef NEUTRAL_K1_WAVES
+#define NEUTRAL_K1_WAVES 3
+#endif
+#ifndef NEUTRAL_K2_WAVES
+#define NEUTRAL_K2_WAVES 4
+#endif
 
 /* ---- small wave utilities -------------------------------------------------- */
 
@@ -92,31 +103,25 @@ __global__ __launch_bounds__(kBlock) void inject_kernel(InjectArgs a) {
 
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
-/* both microscopic cross sections for one energy */
-template <bool kSameTables>
-__device__ __forceinline__ void lookup_cs(const SolveArgs& a, double energy,
-                                          double& micro_scatter, double& micro_absorb) {
-  const int is = cs_bracket(a.scatter_keys, a.scatter_n, energy);
-  micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
-  if (kSameTables) {
-    micro_absorb = micro_scatter;
-  } else {
-    const int ia = cs_bracket(a.absorb_keys, a.absorb_n, energy);
-    micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
+/* one atomic per wave and counter (the cuda analog's block tree reduction +
+ * host finish, cuda/neutral.k:475-493, collapsed into wave reductions) */
+__device__ __forceinline__ void flush_counters(const SolveArgs& a, unsigned nprocessed,
+                                               unsigned nfacets, unsigned ncollisions,
+                                               unsigned ncensus) {
+  const unsigned wf = wave_sum_u32(nfacets);
+  const unsigned wc = wave_sum_u32(ncollisions);
+  const unsigned wp = wave_sum_u32(nprocessed);
+  const unsigned wz = wave_sum_u32(ncensus);
+  if ((threadIdx.x & 63) == 0) {
+    if (wp) atomicAdd(&a.counters->nprocessed, (unsigned long long)wp);
+    if (wf) atomicAdd(&a.counters->nfacets, (unsigned long long)wf);
+    if (wc) atomicAdd(&a.counters->ncollisions, (unsigned long long)wc);
+    if (wz) atomicAdd(&a.counters->ncensus, (unsigned long long)wz);
   }
 }
 
-/* omp3/neutral.c:408-420 */
-__device__ __forceinline__ void update_tallies(const SolveArgs& a, int pcellx, int pcelly,
-                                               double energy_deposition) {
-  const int cellx = pcellx - a.x_off;
-  const int celly = pcelly - a.y_off;
-  unsafeAtomicAdd(&a.tally[celly * a.nx + cellx],
-                  energy_deposition * a.inv_ntotal_particles);
-}
-
 template <bool kSameTables>
-__global__ __launch_bounds__(kBlock) void history_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(SolveArgs a) {
   const int pid = blockIdx.x * kBlock + threadIdx.x;
 
   unsigned nfacets = 0;
@@ -126,179 +131,184 @@ __global__ __launch_bounds__(kBlock) void history_kernel(SolveArgs a) {
 
   if (pid < a.nparticles && !a.p.dead[pid]) { /* omp3/neutral.c:91-93 */
     nprocessed = 1;
-    const uint64_t pkey = a.pid_base + (uint64_t)pid; /* omp3/neutral.c:89 */
-
-    double px = a.p.x[pid];
-    double py = a.p.y[pid];
-    double omega_x = a.p.omega_x[pid];
-    double omega_y = a.p.omega_y[pid];
-    double energy = a.p.energy[pid];
-    double weight = a.p.weight[pid];
-    int pcellx = a.p.cellx[pid];
-    int pcelly = a.p.celly[pid];
-    int dead = 0;
-
-    /* prologue, omp3/neutral.c:103-131 */
-    double local_density =
-        a.density[(pcelly - a.y_off + a.pad) * (a.nx + 2 * a.pad) + (pcellx - a.x_off + a.pad)];
-    double micro_s, micro_a;
-    lookup_cs<kSameTables>(a, energy, micro_s, micro_a);
-    double number_density = (local_density * kAvogadros / kMolarMass);
-    double macro_s = number_density * micro_s * kBarns;
-    double macro_a = number_density * micro_a * kBarns;
-    double speed = speed_of(energy);
-    double energy_deposition = 0.0;
-
-    uint64_t counter = 0;
-    double rn0, rn1;
-    double dt_to_census = a.dt; /* initial == 1: omp3/neutral.c:35-36,127-128 */
-    generate_random_numbers(pkey, a.master_key, counter++, rn0, rn1);
-    double mfp_to_collision = -log(rn0) / macro_s;
-
-    /* event loop, omp3/neutral.c:134-197 */
-    while (dt_to_census > 0.0) {
-      const double cell_mfp = 1.0 / (macro_s + macro_a);
-
-      const int ex = pcellx - a.x_off + a.pad;
-      const int ey = pcelly - a.y_off + a.pad;
-      double distance_to_facet;
-      int x_facet;
-      calc_distance_to_facet(px, py, omega_x, omega_y, speed, a.edgex[ex], a.edgex[ex + 1],
-                             a.edgey[ey], a.edgey[ey + 1], distance_to_facet, x_facet);
-
-      const double distance_to_collision = mfp_to_collision * cell_mfp;
-      const double distance_to_census = speed * dt_to_census;
-
-      if (distance_to_collision < distance_to_facet &&
-          distance_to_collision < distance_to_census) {
-        /* ---- collision, omp3/neutral.c:209-300 ---- */
+    History h;
+    load_particle(h, a, pid);
+    prologue<kSameTables>(h, a);
+    for (;;) { /* omp3/neutral.c:134-197 */
+      decide(h, a);
+      if (h.ev == kEvCollision) {
         ncollisions++;
-        energy_deposition += calculate_energy_deposition(
-            energy, weight, distance_to_collision, number_density, micro_a, micro_s + micro_a);
-        px += distance_to_collision * omega_x;
-        py += distance_to_collision * omega_y;
-
-        const double p_absorb = macro_a / (macro_s + macro_a);
-        double rc0, rc1;
-        generate_random_numbers(pkey, a.master_key, counter++, rc0, rc1);
-
-        if (rc0 < p_absorb) {
-          weight *= (1.0 - p_absorb);
-          if (energy < kMinEnergyOfInterest) {
-            dead = 1;
-            update_tallies(a, pcellx, pcelly, energy_deposition);
-            energy_deposition = 0.0;
-            break;
-          }
-        } else {
-          const double mu_cm = 1.0 - 2.0 * rc1;
-          const double e_new = energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0) /
-                               ((kMassNo + 1.0) * (kMassNo + 1.0));
-          const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / energy) -
-                                          (kMassNo - 1.0) * sqrt(energy / e_new));
-          const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-          const double omega_x_new = (omega_x * cos_theta - omega_y * sin_theta);
-          const double omega_y_new = (omega_x * sin_theta + omega_y * cos_theta);
-          omega_x = omega_x_new;
-          omega_y = omega_y_new;
-          energy = e_new;
+        if (collide<kSameTables>(h, a)) {
+          break;
         }
-
-        lookup_cs<kSameTables>(a, energy, micro_s, micro_a);
-        number_density = (local_density * kAvogadros / kMolarMass);
-        macro_s = number_density * micro_s * kBarns;
-        macro_a = number_density * micro_a * kBarns;
-
-        generate_random_numbers(pkey, a.master_key, counter++, rn0, rn1);
-        mfp_to_collision = -log(rn0) / macro_s;
-        dt_to_census -= distance_to_collision / speed;
-        speed = speed_of(energy);
-      } else if (distance_to_facet < distance_to_census) {
-        /* ---- facet, omp3/neutral.c:303-380 ---- */
+      } else if (h.ev == kEvFacet) {
         nfacets++;
-        mfp_to_collision -= (distance_to_facet / cell_mfp);
-        dt_to_census -= (distance_to_facet / speed);
-        energy_deposition += calculate_energy_deposition(
-            energy, weight, distance_to_facet, number_density, micro_a, micro_s + micro_a);
-        update_tallies(a, pcellx, pcelly, energy_deposition);
-        energy_deposition = 0.0;
-
-        px += distance_to_facet * omega_x;
-        py += distance_to_facet * omega_y;
-
-        if (x_facet) {
-          if (omega_x > 0.0) {
-            if (pcellx >= (a.global_nx - 1)) {
-              omega_x = -omega_x;
-            } else {
-              pcellx++;
-            }
-          } else if (omega_x < 0.0) {
-            if (pcellx <= 0) {
-              omega_x = -omega_x;
-            } else {
-              pcellx--;
-            }
-          }
-        } else {
-          if (omega_y > 0.0) {
-            if (pcelly >= (a.global_ny - 1)) {
-              omega_y = -omega_y;
-            } else {
-              pcelly++;
-            }
-          } else if (omega_y < 0.0) {
-            if (pcelly <= 0) {
-              omega_y = -omega_y;
-            } else {
-              pcelly--;
-            }
-          }
-        }
-
-        local_density = a.density[(pcelly - a.y_off) * a.nx + (pcellx - a.x_off)];
-        number_density = (local_density * kAvogadros / kMolarMass);
-        macro_s = number_density * micro_s * kBarns;
-        macro_a = number_density * micro_a * kBarns;
+        cross_facet(h, a);
       } else {
-        /* ---- census, omp3/neutral.c:383-405 ---- */
-        px += distance_to_census * omega_x;
-        py += distance_to_census * omega_y;
-        mfp_to_collision -= (distance_to_census / cell_mfp);
-        energy_deposition += calculate_energy_deposition(
-            energy, weight, distance_to_census, number_density, micro_a, micro_s + micro_a);
-        update_tallies(a, pcellx, pcelly, energy_deposition);
-        dt_to_census = 0.0;
-        ncensus = 1;
+        if (h.ev == kEvCensus) {
+          ncensus = 1;
+          census(h, a);
+        }
         break;
       }
     }
-
-    a.p.x[pid] = px;
-    a.p.y[pid] = py;
-    a.p.omega_x[pid] = omega_x;
-    a.p.omega_y[pid] = omega_y;
-    a.p.energy[pid] = energy;
-    a.p.weight[pid] = weight;
-    a.p.dt_to_census[pid] = dt_to_census;
-    a.p.mfp_to_collision[pid] = mfp_to_collision;
-    a.p.cellx[pid] = pcellx;
-    a.p.celly[pid] = pcelly;
-    a.p.dead[pid] = dead;
+    store_particle(h, a, pid);
   }
+  flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
+}
 
-  /* event counters: wave reduction, one atomic per wave and counter
-   * (the cuda analog's block tree reduction + host finish, cuda/neutral.k:475-493) */
-  const unsigned wf = wave_sum_u32(nfacets);
-  const unsigned wc = wave_sum_u32(ncollisions);
-  const unsigned wp = wave_sum_u32(nprocessed);
-  const unsigned wz = wave_sum_u32(ncensus);
-  if ((threadIdx.x & 63) == 0) {
-    if (wz) atomicAdd(&a.counters->ncensus, (unsigned long long)wz);
-    if (wp) atomicAdd(&a.counters->nprocessed, (unsigned long long)wp);
-    if (wf) atomicAdd(&a.counters->nfacets, (unsigned long long)wf);
-    if (wc) atomicAdd(&a.counters->ncollisions, (unsigned long long)wc);
+/* ---- K2: event-regrouped persistent waves ----------------------------------- */
+
+/*
+ * K1 leaves most of a wave idle whenever histories differ: in csp the few lanes
+ * inside the dense block run hundreds of ~4000-cycle collisions while the other
+ * lanes, done after ~60 cheap facets, wait (0.74 ns/collision against 0.027 in
+ * the all-colliding scatter deck, profiles/r01/ablate_tally.log).  K2 keeps the
+ * one-lane-one-history register residency but decouples lanes from particle
+ * ids:
+ *
+ *   - persistent waves pull particle ids from a global queue in chunks
+ *     (one atomicAdd per kQueueChunk ids);
+ *   - every lane always knows which PASS it needs next: REFILL (no particle),
+ *     STREAM (next event is a facet or the census) or COLLIDE;
+ *   - each iteration the wave ballots the three populations and runs ONE pass,
+ *     for the lanes that want it only; the others stay parked in registers.
+ *     Expensive collisions wait until they fill most of the wave, cheap facet
+ *     crossings run whenever any lane wants one, and a finished lane is re-used
+ *     instead of idling until the slowest history of its wave ends.
+ *
+ * A lane runs exactly the event sequence K1 would run for the same particle
+ * (same neutral_history.h bodies, same RNG counters), so particle end states
+ * are bit-identical to K1; only the order of the tally atomics differs.
+ * Exit: the queue head only grows, a wave leaves when the queue is drained and
+ * none of its lanes holds a particle -- every wave reaches that state.
+ */
+constexpr int kQueueChunk = 128;
+#ifndef NEUTRAL_REFILL_MIN
+#define NEUTRAL_REFILL_MIN 8
+#endif
+#ifndef NEUTRAL_COLLIDE_MIN
+#define NEUTRAL_COLLIDE_MIN 48
+#endif
+constexpr int kRefillMin = NEUTRAL_REFILL_MIN;   /* REFILL pass once this many lanes are empty */
+constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many lanes wait */
+
+enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {
+  /* number of set bits of mask below this lane */
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <bool kSameTables>
+__global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kernel(SolveArgs a) {
+  unsigned nfacets = 0;
+  unsigned ncollisions = 0;
+  unsigned nprocessed = 0;
+  unsigned ncensus = 0;
+
+  History h;
+  int pid = -1;
+  int want = kWantRefill;
+  h.ev = kEvEnd;
+
+  /* wave-private slice of the particle queue (wave-uniform values) */
+  int cur = 0;
+  int end = 0;
+  bool drained = false;
+
+  for (;;) {
+    const unsigned long long m_refill = __ballot(want == kWantRefill);
+    const unsigned long long m_stream = __ballot(want == kWantStream);
+    const unsigned long long m_collide = __ballot(want == kWantCollide);
+    const int n_refill = drained ? 0 : __popcll(m_refill);
+    const int n_stream = __popcll(m_stream);
+    const int n_collide = __popcll(m_collide);
+    if (n_refill + n_stream + n_collide == 0) {
+      break;
+    }
+
+    /* Pass choice.  A collision costs ~7x a facet crossing, so collisions wait
+     * (parked in registers) until they fill most of the wave; cheap STREAM
+     * passes run as long as any lane wants one; REFILL runs once enough lanes
+     * are empty to amortise the prologue, or when nothing else can run. */
+    int pass;
+    if (n_collide >= kCollideMin) {
+      pass = kWantCollide;
+    } else if (n_refill >= kRefillMin) {
+      pass = kWantRefill;
+    } else if (n_stream > 0) {
+      pass = kWantStream;
+    } else if (n_refill > 0) {
+      pass = kWantRefill;
+    } else {
+      pass = kWantCollide;
+    }
+
+    if (pass == kWantRefill) {
+      /* ---- REFILL pass: hand fresh particle ids to the empty lanes ---- */
+      if (cur >= end) {
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) {
+          base = (int)atomicAdd(&a.counters->queue_head, (unsigned)kQueueChunk);
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        /* the head can overshoot nparticles by at most (#waves * chunk) */
+        if (base >= a.nparticles || base < 0) {
+          drained = true;
+          cur = end = 0;
+        } else {
+          cur = base;
+          end = (base + kQueueChunk < a.nparticles) ? base + kQueueChunk : a.nparticles;
+        }
+      }
+      if (!drained) {
+        const int mine = cur + lane_rank(m_refill);
+        const bool take = (want == kWantRefill) && (mine < end);
+        const int avail = end - cur;
+        cur += (n_refill < avail) ? n_refill : avail;
+        if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
+          pid = mine;
+          nprocessed++;
+          load_particle(h, a, pid);
+          prologue<kSameTables>(h, a);
+          decide(h, a);
+          want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+        }
+      }
+    } else if (pass == kWantCollide) {
+      /* ---- COLLIDE pass ---- */
+      if (want == kWantCollide) {
+        ncollisions++;
+        if (collide<kSameTables>(h, a)) {
+          store_particle(h, a, pid);
+          want = kWantRefill;
+        } else {
+          decide(h, a);
+          want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+        }
+      }
+    } else {
+      /* ---- STREAM pass: facet crossings, census, end of history ---- */
+      if (want == kWantStream) {
+        if (h.ev == kEvFacet) {
+          nfacets++;
+          cross_facet(h, a);
+          decide(h, a);
+          want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+        } else {
+          if (h.ev == kEvCensus) {
+            ncensus++;
+            census(h, a);
+          }
+          store_particle(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
+          want = kWantRefill;
+        }
+      }
+    }
   }
+  flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
 }
 
 /* ---- table comparison ------------------------------------------------------ */
@@ -393,11 +403,44 @@ hipError_t launch_inject(const InjectArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+/* blocks of kBlock threads the device keeps resident for a kernel */
+template <typename K>
+static int resident_blocks(K kernel) {
+  int dev = 0;
+  int cus = 256;
+  int per_cu = 2;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
+      per_cu < 1) {
+    per_cu = 2;
+  }
+  return cus * per_cu;
+}
+
 hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
   if (a.nparticles <= 0) {
     return hipSuccess;
   }
-  (void)variant; /* K2 (event-sorted) joins here */
+  if (variant == kVariantEventSorted) {
+    /* persistent waves: as many workgroups as stay resident, never more than
+     * there are chunks of work; no workgroup depends on another, so an
+     * over-estimate only queues the surplus */
+    const int chunks = (a.nparticles + kQueueChunk - 1) / kQueueChunk;
+    const int want_blocks = (chunks + (kBlock / 64) - 1) / (kBlock / 64);
+    int grid = a.same_tables ? resident_blocks(history_regroup_kernel<true>)
+                             : resident_blocks(history_regroup_kernel<false>);
+    if (grid > want_blocks) {
+      grid = want_blocks;
+    }
+    if (a.same_tables) {
+      hipLaunchKernelGGL(history_regroup_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL(history_regroup_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+    }
+    return hipGetLastError();
+  }
   const int grid = (a.nparticles + kBlock - 1) / kBlock;
   if (a.same_tables) {
     hipLaunchKernelGGL(history_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, a);

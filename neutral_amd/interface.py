@@ -18,9 +18,14 @@ from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
+# torch must be imported before libneutral_hip.so is loaded: the PyTorch-ROCm
+# wheel bundles its own libamdhip64, and one process must hold exactly one HIP
+# runtime (loading the system one first makes every later device call fail).
+import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneutral_hip.so")
+# NEUTRAL_HIP_LIB selects another build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get("NEUTRAL_HIP_LIB") or os.path.join(_HERE, "libneutral_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
