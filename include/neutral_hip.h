@@ -199,12 +199,14 @@ void neutral_hip_synchronize(void);
  *              two Threefry2x64-20 words; rn2 = the two (0,1] doubles of
  *              generate_random_numbers (omp3/neutral.c:632-652)
  *   cs_lookup: microscopic_cs_for_energy (omp3/neutral.c:498-517) of `cs`
- *              ([device] table) at n energies -> value and bracket index
+ *              ([device] table) at n energies -> value and bracket index;
+ *              use_index = 1 searches through the exponent-bucketed index the
+ *              history kernels use, 0 by plain bisection
  *   distance_to_facet: in9 = n rows {x, y, omega_x, omega_y, speed, edgex[c],
  *              edgex[c+1], edgey[c], edgey[c+1]} (omp3/neutral.c:423-471) */
 void neutral_hip_probe_threefry(const uint64_t* in3, uint64_t* out2, double* rn2, int n);
 void neutral_hip_probe_cs_lookup(const NeutralHipCrossSection* cs, const double* energy,
-                                 double* value, int* index, int n);
+                                 double* value, int* index, int n, int use_index);
 void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, int* x_facet,
                                          int n);
 /* Library/ABI version, bumped on any signature change. */

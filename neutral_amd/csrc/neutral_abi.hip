@@ -37,7 +37,11 @@ int within_tolerance(const double expected, const double result, const double to
     }                                                                                \
   } while (0)
 
+#include "neutral_device.h"
+
 namespace {
+
+constexpr int kMaxIndexBuckets = 16384; /* u16 entries: 32 KB of LDS at most */
 
 struct State {
   hipStream_t stream = nullptr;
@@ -51,6 +55,7 @@ struct State {
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
   int* d_flag = nullptr;
+  unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_stop = nullptr;
 };
@@ -66,6 +71,9 @@ void ensure_scratch() {
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
   HIP_CHECK(hipMalloc((void**)&g.d_counters, sizeof(neutral::StepCounters)));
   HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
+  for (unsigned short*& d : g.d_index) {
+    HIP_CHECK(hipMalloc((void**)&d, sizeof(unsigned short) * (kMaxIndexBuckets + 1)));
+  }
   HIP_CHECK(hipEventCreate(&g.ev_start));
   HIP_CHECK(hipEventCreate(&g.ev_stop));
   g.scratch_device = dev;
@@ -93,6 +101,39 @@ void* device_zalloc(size_t bytes) {
   HIP_CHECK(hipMemsetAsync(p, 0, bytes ? bytes : 1, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
   return p;
+}
+
+/* Builds the exponent-bucketed index of one key array into d_start (see
+ * neutral_device.h).  Returns a null index when the table cannot be indexed:
+ * more than 65 535 entries (u16 starts) or non-positive first key (bit patterns
+ * of non-positive doubles do not order like their values). */
+neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_start) {
+  neutral::CsIndex ix = {nullptr, 0, 0, 0};
+  if (n < 2 || n > 65535) {
+    return ix;
+  }
+  double ends[2];
+  HIP_CHECK(hipMemcpyAsync(&ends[0], d_keys, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  HIP_CHECK(hipMemcpyAsync(&ends[1], d_keys + (n - 1), sizeof(double), hipMemcpyDeviceToHost,
+                           g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  if (!(ends[0] > 0.0) || !(ends[1] > ends[0])) {
+    return ix;
+  }
+  long long lo_bits, hi_bits;
+  memcpy(&lo_bits, &ends[0], sizeof(lo_bits));
+  memcpy(&hi_bits, &ends[1], sizeof(hi_bits));
+  int shift = 44; /* 256 buckets per binade */
+  while (((hi_bits >> shift) - (lo_bits >> shift) + 1) > kMaxIndexBuckets) {
+    shift++;
+  }
+  ix.shift = shift;
+  ix.base = lo_bits >> shift;
+  ix.nbuckets = (int)((hi_bits >> shift) - ix.base + 1);
+  HIP_CHECK(neutral::launch_build_cs_index(d_keys, n, ix.shift, ix.base, ix.nbuckets, d_start,
+                                           g.stream));
+  ix.start = d_start;
+  return ix;
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -222,6 +263,26 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.absorb_values = cs_absorb_table->values;
   a.absorb_n = cs_absorb_table->nentries;
   a.same_tables = same;
+  /* bucketed indexes, rebuilt per call like the equality test (tables may change) */
+  neutral::CsIndex ix_s = build_index(cs_scatter_table->keys, cs_scatter_table->nentries,
+                                      g.d_index[0]);
+  neutral::CsIndex ix_a = ix_s;
+  if (!same) {
+    ix_a = build_index(cs_absorb_table->keys, cs_absorb_table->nentries, g.d_index[1]);
+    if (ix_a.start && ix_s.start && ix_a.shift != ix_s.shift) {
+      ix_a.start = nullptr; /* one shift per launch: the absorb table falls back to bisection */
+    }
+    if (!ix_s.start && ix_a.start) {
+      ix_s.shift = ix_a.shift;
+    }
+  }
+  a.scatter_index = ix_s.start;
+  a.scatter_index_n = ix_s.nbuckets;
+  a.scatter_index_base = ix_s.base;
+  a.absorb_index = ix_a.start;
+  a.absorb_index_n = ix_a.nbuckets;
+  a.absorb_index_base = ix_a.base;
+  a.index_shift = ix_s.start ? ix_s.shift : ix_a.shift;
   a.tally = energy_deposition_tally;
   a.counters = g.d_counters;
 
@@ -503,11 +564,16 @@ void neutral_hip_probe_threefry(const uint64_t* in3, uint64_t* out2, double* rn2
 }
 
 void neutral_hip_probe_cs_lookup(const NeutralHipCrossSection* cs, const double* energy,
-                                 double* value, int* index, int n) {
+                                 double* value, int* index, int n, int use_index) {
   double* d_e = stage_in(energy, (size_t)n);
   double* d_v = stage_in((const double*)nullptr, (size_t)n);
   int* d_i = stage_in((const int*)nullptr, (size_t)n);
-  HIP_CHECK(neutral::launch_probe_cs(cs->keys, cs->values, cs->nentries, d_e, d_v, d_i, n,
+  ensure_scratch();
+  neutral::CsIndex ix = {nullptr, 0, 0, 0};
+  if (use_index) {
+    ix = build_index(cs->keys, cs->nentries, g.d_index[0]);
+  }
+  HIP_CHECK(neutral::launch_probe_cs(cs->keys, cs->values, cs->nentries, d_e, d_v, d_i, n, ix,
                                      g.stream));
   stage_out(value, d_v, (size_t)n);
   stage_out(index, d_i, (size_t)n);

@@ -56,16 +56,37 @@ __device__ __forceinline__ void update_tallies(const SolveArgs& a, int pcellx, i
 #endif
 }
 
+/* Where a kernel variant keeps the bucketed cs indexes: K1 reads them from
+ * global memory (L1/L2 hits), the persistent K2 stages them in LDS once per
+ * workgroup.  A null pointer means "no index": plain bisection. */
+template <typename IndexPtr>
+struct CsLookup {
+  IndexPtr scatter_index;
+  IndexPtr absorb_index;
+};
+
+template <typename IndexPtr>
+__device__ __forceinline__ int bracket_of(const double* keys, int n, IndexPtr index, int index_n,
+                                          int shift, long long base, double energy) {
+  if (index) {
+    return cs_bracket_indexed(keys, n, index, index_n, shift, base, energy);
+  }
+  return cs_bracket(keys, n, energy);
+}
+
 /* both microscopic cross sections for one energy */
-template <bool kSameTables>
-__device__ __forceinline__ void lookup_cs(const SolveArgs& a, double energy, double& micro_scatter,
+template <bool kSameTables, typename IndexPtr>
+__device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<IndexPtr>& ix,
+                                          double energy, double& micro_scatter,
                                           double& micro_absorb) {
-  const int is = cs_bracket(a.scatter_keys, a.scatter_n, energy);
+  const int is = bracket_of(a.scatter_keys, a.scatter_n, ix.scatter_index, a.scatter_index_n,
+                            a.index_shift, a.scatter_index_base, energy);
   micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
   if (kSameTables) {
     micro_absorb = micro_scatter;
   } else {
-    const int ia = cs_bracket(a.absorb_keys, a.absorb_n, energy);
+    const int ia = bracket_of(a.absorb_keys, a.absorb_n, ix.absorb_index, a.absorb_index_n,
+                              a.index_shift, a.absorb_index_base, energy);
     micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
   }
 }
@@ -105,11 +126,12 @@ __device__ __forceinline__ void store_particle(const History& h, const SolveArgs
 }
 
 /* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */
-template <bool kSameTables>
-__device__ __forceinline__ void prologue(History& h, const SolveArgs& a) {
+template <bool kSameTables, typename IndexPtr>
+__device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
+                                         const CsLookup<IndexPtr>& ix) {
   h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
                               (h.cellx - a.x_off + a.pad)];
-  lookup_cs<kSameTables>(a, h.energy, h.micro_s, h.micro_a);
+  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
   macroscopic_from_density(h);
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
@@ -147,8 +169,9 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables>
-__device__ __forceinline__ bool collide(History& h, const SolveArgs& a) {
+template <bool kSameTables, typename IndexPtr>
+__device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
+                                        const CsLookup<IndexPtr>& ix) {
   const double distance_to_collision = h.distance;
   h.energy_deposition +=
       calculate_energy_deposition(h.energy, h.weight, distance_to_collision, h.number_density,
@@ -184,7 +207,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a) {
     h.energy = e_new;
   }
 
-  lookup_cs<kSameTables>(a, h.energy, h.micro_s, h.micro_a);
+  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
   macroscopic_from_density(h);
 
   double rn0, rn1;

@@ -81,6 +81,14 @@ struct SolveArgs {
   const double* absorb_values;
   int absorb_n;
   int same_tables; /* both tables have identical contents: search once */
+  /* exponent-bucketed indexes over the key arrays (start == null: none) */
+  const unsigned short* scatter_index;
+  int scatter_index_n;
+  long long scatter_index_base;
+  const unsigned short* absorb_index;
+  int absorb_index_n;
+  long long absorb_index_base;
+  int index_shift;
   double* tally;
   StepCounters* counters;
 };
@@ -97,12 +105,17 @@ hipError_t launch_tables_equal(const double* ka, const double* va, const double*
                                const double* vb, int n, int* d_flag, hipStream_t stream);
 
 
+/* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
+hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,
+                                 int nbuckets, unsigned short* start, hipStream_t stream);
+
 /* unit probes of the device building blocks (all pointers [device]) */
 hipError_t launch_probe_threefry(const uint64_t* in, uint64_t* out, double* rn, int n,
                                  hipStream_t stream);
+struct CsIndex;
 hipError_t launch_probe_cs(const double* keys, const double* values, int nentries,
                            const double* energy, double* value, int* index, int n,
-                           hipStream_t stream);
+                           const CsIndex& ix, hipStream_t stream);
 hipError_t launch_probe_facet(const double* in, double* dist, int* x_facet, int n,
                               hipStream_t stream);
 

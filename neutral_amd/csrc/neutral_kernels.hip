@@ -131,14 +131,15 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
 
   if (pid < a.nparticles && !a.p.dead[pid]) { /* omp3/neutral.c:91-93 */
     nprocessed = 1;
+    const CsLookup<const unsigned short*> ix{a.scatter_index, a.absorb_index};
     History h;
     load_particle(h, a, pid);
-    prologue<kSameTables>(h, a);
+    prologue<kSameTables>(h, a, ix);
     for (;;) { /* omp3/neutral.c:134-197 */
       decide(h, a);
       if (h.ev == kEvCollision) {
         ncollisions++;
-        if (collide<kSameTables>(h, a)) {
+        if (collide<kSameTables>(h, a, ix)) {
           break;
         }
       } else if (h.ev == kEvFacet) {
@@ -208,6 +209,27 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
 
+  /* stage the bucketed cs index(es) in LDS: nbuckets+1 u16 entries each */
+  extern __shared__ unsigned short lds_index[];
+  CsLookup<const unsigned short*> ix{nullptr, nullptr};
+  {
+    int used = 0;
+    if (a.scatter_index) {
+      for (int i = threadIdx.x; i <= a.scatter_index_n; i += kBlock) {
+        lds_index[i] = a.scatter_index[i];
+      }
+      ix.scatter_index = lds_index;
+      used = a.scatter_index_n + 1;
+    }
+    if (!kSameTables && a.absorb_index) {
+      for (int i = threadIdx.x; i <= a.absorb_index_n; i += kBlock) {
+        lds_index[used + i] = a.absorb_index[i];
+      }
+      ix.absorb_index = lds_index + used;
+    }
+    __syncthreads();
+  }
+
   History h;
   int pid = -1;
   int want = kWantRefill;
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
           pid = mine;
           nprocessed++;
           load_particle(h, a, pid);
-          prologue<kSameTables>(h, a);
+          prologue<kSameTables>(h, a, ix);
           decide(h, a);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       /* ---- COLLIDE pass ---- */
       if (want == kWantCollide) {
         ncollisions++;
-        if (collide<kSameTables>(h, a)) {
+        if (collide<kSameTables>(h, a, ix)) {
           store_particle(h, a, pid);
           want = kWantRefill;
         } else {
@@ -309,6 +331,33 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
     }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
+}
+
+/* ---- bucketed cs index -------------------------------------------------------- */
+
+__global__ __launch_bounds__(kBlock) void build_cs_index_kernel(const double* keys, int n,
+                                                                int shift, long long base,
+                                                                int nbuckets,
+                                                                unsigned short* start) {
+  const int b = blockIdx.x * kBlock + threadIdx.x;
+  if (b > nbuckets) {
+    return;
+  }
+  /* lowest energy of bucket b; start[b] = last key <= it, clamped to [0, n-2] */
+  const double e_lo = __longlong_as_double((base + (long long)b) << shift);
+  int lo = 0; /* first index with keys[i] > e_lo, by bisection over [0, n] */
+  int hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] > e_lo) {
+      hi = mid;
+    } else {
+      lo = mid + 1;
+    }
+  }
+  int s = lo - 1;
+  s = (s < 0) ? 0 : ((s > n - 2) ? n - 2 : s);
+  start[b] = (unsigned short)s;
 }
 
 /* ---- table comparison ------------------------------------------------------ */
@@ -347,10 +396,16 @@ __global__ __launch_bounds__(kBlock) void probe_threefry_kernel(const uint64_t* 
 
 __global__ __launch_bounds__(kBlock) void probe_cs_kernel(const double* keys, const double* values,
                                                            int nentries, const double* energy,
-                                                           double* value, int* index, int n) {
+                                                           double* value, int* index, int n,
+                                                           const unsigned short* index_start,
+                                                           int index_n, int index_shift,
+                                                           long long index_base) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
-    const int ind = cs_bracket(keys, nentries, energy[i]);
+    /* index_start == null probes the plain bisection */
+    const int ind = index_start ? cs_bracket_indexed(keys, nentries, index_start, index_n,
+                                                     index_shift, index_base, energy[i])
+                                : cs_bracket(keys, nentries, energy[i]);
     index[i] = ind;
     value[i] = cs_interpolate(keys, values, ind, energy[i]);
   }
@@ -381,9 +436,17 @@ hipError_t launch_probe_threefry(const uint64_t* in, uint64_t* out, double* rn, 
 
 hipError_t launch_probe_cs(const double* keys, const double* values, int nentries,
                            const double* energy, double* value, int* index, int n,
-                           hipStream_t stream) {
+                           const CsIndex& ix, hipStream_t stream) {
   hipLaunchKernelGGL(probe_cs_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                     keys, values, nentries, energy, value, index, n);
+                     keys, values, nentries, energy, value, index, n, ix.start, ix.nbuckets,
+                     ix.shift, ix.base);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,
+                                 int nbuckets, unsigned short* start, hipStream_t stream) {
+  hipLaunchKernelGGL(build_cs_index_kernel, dim3((nbuckets + 1 + kBlock - 1) / kBlock),
+                     dim3(kBlock), 0, stream, keys, n, shift, base, nbuckets, start);
   return hipGetLastError();
 }
 
@@ -434,10 +497,14 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     if (grid > want_blocks) {
       grid = want_blocks;
     }
+    size_t lds = a.scatter_index ? sizeof(unsigned short) * (a.scatter_index_n + 1) : 0;
+    if (!a.same_tables && a.absorb_index) {
+      lds += sizeof(unsigned short) * (a.absorb_index_n + 1);
+    }
     if (a.same_tables) {
-      hipLaunchKernelGGL(history_regroup_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, a);
+      hipLaunchKernelGGL(history_regroup_kernel<true>, dim3(grid), dim3(kBlock), lds, stream, a);
     } else {
-      hipLaunchKernelGGL(history_regroup_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+      hipLaunchKernelGGL(history_regroup_kernel<false>, dim3(grid), dim3(kBlock), lds, stream, a);
     }
     return hipGetLastError();
   }

@@ -116,7 +116,7 @@ _lib.neutral_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
 _lib.neutral_hip_abi_version.restype = C.c_int
 _lib.neutral_hip_probe_threefry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_cs_lookup.argtypes = [C.POINTER(CrossSection), C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_int]
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 _lib.neutral_hip_probe_distance_to_facet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int]
 
@@ -217,12 +217,12 @@ def probe_threefry(counter_pkey_mkey: np.ndarray):
     return words, rn
 
 
-def probe_cs_lookup(cs: CrossSection, energies: np.ndarray):
+def probe_cs_lookup(cs: CrossSection, energies: np.ndarray, use_index: bool = True):
     e = np.ascontiguousarray(energies, dtype=np.float64)
     value = np.zeros(e.size, dtype=np.float64)
     index = np.zeros(e.size, dtype=np.int32)
     _lib.neutral_hip_probe_cs_lookup(C.byref(cs), e.ctypes.data, value.ctypes.data,
-                                     index.ctypes.data, e.size)
+                                     index.ctypes.data, e.size, 1 if use_index else 0)
     return value, index
 
 

@@ -70,7 +70,10 @@ def test_cs_lookup_matches_oracle(iface, pins, cs):
         np.array([e["energy"] for e in pins["cs_lookup"]]),
         keys[:-1][::37], np.nextafter(keys[1:][::41], 0.0),
         np.exp(rng.uniform(np.log(keys[0] * 1.0001), np.log(keys[-1] * 0.9999), 100000))])
-    value, index = iface.probe_cs_lookup(table, es)
+    value, index = iface.probe_cs_lookup(table, es, use_index=True)
+    value_b, index_b = iface.probe_cs_lookup(table, es, use_index=False)
+    # the exponent-bucketed search and the plain bisection find the same bracket
+    assert np.array_equal(index, index_b) and np.array_equal(value, value_b)
     host = ob.CsTable(keys, values)
     for i in list(range(len(pins["cs_lookup"]))) + list(range(5, len(es), 97)):
         v, ind = host.lookup(float(es[i]))
@@ -80,6 +83,32 @@ def test_cs_lookup_matches_oracle(iface, pins, cs):
         assert ind == e["index"] and v == pytest.approx(e["value"], rel=1e-14)
     # whole-array check of the bracket against numpy
     assert np.array_equal(index, np.searchsorted(keys, es, side="right") - 1)
+
+
+def test_cs_lookup_index_on_awkward_tables(iface):
+    """Bucketed index on tables unlike the shipped one: tiny, clustered keys,
+    many binades, keys on bucket boundaries (powers of two)."""
+    import torch
+    rng = np.random.default_rng(9)
+    tables = [
+        np.array([1.0, 2.0]),
+        np.array([0.5, 1.0, 2.0, 4.0, 8.0, 1024.0]),
+        np.sort(np.concatenate([1.0 + rng.random(3000) * 1e-9, [0.25, 7.0]])),
+        np.sort(np.exp(rng.uniform(np.log(1e-300), np.log(1e300), 5000))),
+        np.cumsum(rng.random(60000)) + 1e-3,
+    ]
+    for keys in tables:
+        keys = np.unique(keys)
+        values = rng.random(keys.size) * 100.0
+        dk, dv = torch.from_numpy(keys).cuda(), torch.from_numpy(values).cuda()
+        table = iface.CrossSection(dk.data_ptr(), dv.data_ptr(), keys.size)
+        es = np.concatenate([keys[:-1], np.nextafter(keys[1:], 0.0),
+                             rng.uniform(keys[0], keys[-1], 20000)])
+        es = es[(es >= keys[0]) & (es < keys[-1])]
+        v1, i1 = iface.probe_cs_lookup(table, es, use_index=True)
+        v0, i0 = iface.probe_cs_lookup(table, es, use_index=False)
+        assert np.array_equal(i1, np.searchsorted(keys, es, side="right") - 1)
+        assert np.array_equal(i1, i0) and np.array_equal(v1, v0)
 
 
 def test_distance_to_facet_matches_oracle(iface):
