@@ -140,7 +140,9 @@ void move_host_buffer_to_device(const size_t len, double** src, double** dst);
 
 enum {
   NEUTRAL_HIP_VARIANT_OVER_PARTICLE = 0, /* one lane owns a history (default) */
-  NEUTRAL_HIP_VARIANT_EVENT_SORTED = 1   /* lanes regrouped by next event */
+  NEUTRAL_HIP_VARIANT_EVENT_SORTED = 1,  /* lanes regrouped by next event */
+  NEUTRAL_HIP_VARIANT_TILED = 2          /* tile-sorted streaming with the tally tile in
+                                            LDS, then the event-regrouped collision kernel */
 };
 
 typedef struct {

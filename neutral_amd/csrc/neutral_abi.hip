@@ -58,6 +58,11 @@ struct State {
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_stop = nullptr;
+  /* workspace of the tiled variant, grown on demand */
+  neutral::TiledArgs tiled = {};
+  int tiled_particles = 0;
+  int tiled_tiles = 0;
+  int tiled_chunks = 0;
 };
 
 State g;
@@ -87,7 +92,8 @@ void read_variant_env() {
   const char* v = getenv("NEUTRAL_HIP_VARIANT");
   if (v && *v) {
     const int iv = atoi(v);
-    if (iv == NEUTRAL_HIP_VARIANT_OVER_PARTICLE || iv == NEUTRAL_HIP_VARIANT_EVENT_SORTED) {
+    if (iv == NEUTRAL_HIP_VARIANT_OVER_PARTICLE || iv == NEUTRAL_HIP_VARIANT_EVENT_SORTED ||
+        iv == NEUTRAL_HIP_VARIANT_TILED) {
       g.variant = iv;
     } else {
       fprintf(stderr, "libneutral_hip: ignoring NEUTRAL_HIP_VARIANT=%s\n", v);
@@ -134,6 +140,41 @@ neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_star
                                            g.stream));
   ix.start = d_start;
   return ix;
+}
+
+/* (Re)allocates the tiled variant's workspace for this problem size. */
+void ensure_tiled_workspace(int nx, int ny, int nparticles) {
+  int tx, ty, max_chunks;
+  neutral::tiled_geometry(nx, ny, nparticles, &tx, &ty, &max_chunks);
+  neutral::TiledArgs& t = g.tiled;
+  if (nparticles > g.tiled_particles) {
+    if (t.order) HIP_CHECK(hipFree(t.order));
+    if (t.collide_queue) HIP_CHECK(hipFree(t.collide_queue));
+    HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * (size_t)nparticles));
+    HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * (size_t)nparticles));
+    g.tiled_particles = nparticles;
+  }
+  if (tx * ty > g.tiled_tiles) {
+    if (t.tile_count) HIP_CHECK(hipFree(t.tile_count));
+    if (t.tile_offset) HIP_CHECK(hipFree(t.tile_offset));
+    if (t.tile_cursor) HIP_CHECK(hipFree(t.tile_cursor));
+    HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * (size_t)(tx * ty)));
+    HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty)));
+    HIP_CHECK(hipMalloc((void**)&t.tile_cursor, sizeof(unsigned) * (size_t)(tx * ty)));
+    g.tiled_tiles = tx * ty;
+  }
+  if (max_chunks > g.tiled_chunks) {
+    if (t.chunks) HIP_CHECK(hipFree(t.chunks));
+    HIP_CHECK(hipMalloc((void**)&t.chunks, sizeof(uint4) * (size_t)max_chunks));
+    g.tiled_chunks = max_chunks;
+  }
+  if (!t.ctrl) {
+    HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 4));
+  }
+  t.tiles_x = tx;
+  t.tiles_y = ty;
+  t.ntiles = tx * ty;
+  t.max_chunks = max_chunks;
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -285,10 +326,33 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.index_shift = ix_s.start ? ix_s.shift : ix_a.shift;
   a.tally = energy_deposition_tally;
   a.counters = g.d_counters;
+  a.queue = nullptr;
+  a.queue_len = nullptr;
 
   HIP_CHECK(hipMemsetAsync(g.d_counters, 0, sizeof(neutral::StepCounters), g.stream));
+  const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
+  if (tiled) {
+    if (pad != 0) {
+      fprintf(stderr, "libneutral_hip: the tiled variant needs pad = 0 (as main.c:33 sets).\n");
+      exit(EXIT_FAILURE);
+    }
+    ensure_tiled_workspace(nx, ny, a.nparticles);
+    /* the tally window takes 128 KB of the 160 KB of LDS: an index that does
+     * not fit next to it stays in HBM-side bisection (same brackets) */
+    const size_t lds_limit = 160 * 1024 - 64;
+    if (neutral::tiled_lds_bytes(a) > lds_limit) {
+      a.absorb_index = nullptr;
+    }
+    if (neutral::tiled_lds_bytes(a) > lds_limit) {
+      a.scatter_index = nullptr;
+    }
+  }
   HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
-  HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
+  if (tiled) {
+    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream));
+  } else {
+    HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
+  }
   HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
 
   neutral::StepCounters h;
@@ -471,7 +535,7 @@ uint64_t neutral_hip_get_pid_base(void) { return g.pid_base; }
 
 int neutral_hip_set_variant(int variant) {
   if (variant != NEUTRAL_HIP_VARIANT_OVER_PARTICLE &&
-      variant != NEUTRAL_HIP_VARIANT_EVENT_SORTED) {
+      variant != NEUTRAL_HIP_VARIANT_EVENT_SORTED && variant != NEUTRAL_HIP_VARIANT_TILED) {
     return 1;
   }
   g.variant = variant;

@@ -43,18 +43,48 @@ struct History {
   int ev;
 };
 
-/* omp3/neutral.c:408-420 */
-__device__ __forceinline__ void update_tallies(const SolveArgs& a, int pcellx, int pcelly,
-                                               double energy_deposition) {
-  const int cellx = pcellx - a.x_off;
-  const int celly = pcelly - a.y_off;
+/* ---- tally policies: WHERE update_tallies (omp3/neutral.c:408-420) adds -------- */
+
+/* straight to the mesh in HBM: one global_atomic_add_f64 per tally */
+struct GlobalTally {
+  __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
+                                             double energy_deposition) const {
+    const int cellx = pcellx - a.x_off;
+    const int celly = pcelly - a.y_off;
 #if defined(NEUTRAL_EXP_NO_TALLY)
-  /* timing experiment only: keep the value alive, drop the memory operation */
-  if (energy_deposition == 1.2345e300) a.tally[celly * a.nx + cellx] = energy_deposition;
+    /* timing experiment only: keep the value alive, drop the memory operation */
+    if (energy_deposition == 1.2345e300) a.tally[celly * a.nx + cellx] = energy_deposition;
 #else
-  unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], energy_deposition * a.inv_ntotal_particles);
+    unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], energy_deposition * a.inv_ntotal_particles);
 #endif
-}
+  }
+};
+
+/* into a W x W window of the mesh held in LDS (ds_add_f64) when the cell lies
+ * inside it, to HBM otherwise; the owner flushes the window to the mesh */
+typedef __attribute__((address_space(3))) double lds_double;
+
+template <int W>
+struct WindowTally {
+  lds_double* window; /* LDS, W*W, row-major */
+  int ox;         /* local cell coordinates of window element (0,0) */
+  int oy;
+  __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
+                                             double energy_deposition) const {
+    const int cellx = pcellx - a.x_off;
+    const int celly = pcelly - a.y_off;
+    const unsigned lx = (unsigned)(cellx - ox);
+    const unsigned ly = (unsigned)(celly - oy);
+    const double v = energy_deposition * a.inv_ntotal_particles;
+    if (lx < (unsigned)W && ly < (unsigned)W) {
+      /* ds_add_f64, no return value */
+      (void)__hip_atomic_fetch_add(&window[ly * W + lx], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], v);
+    }
+  }
+};
 
 /* Where a kernel variant keeps the bucketed cs indexes: K1 reads them from
  * global memory (L1/L2 hits), the persistent K2 stages them in LDS once per
@@ -142,6 +172,26 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   h.mfp_to_collision = -log(rn0) / h.macro_s;
 }
 
+/* Re-derives the locals of a history that another kernel suspended at a loop
+ * head after its streaming phase (no collision yet): the particle record holds
+ * x, y, omega, energy, weight, cell AND the live dt_to_census / mfp_to_collision;
+ * density, cross sections and speed are pure functions of those; exactly one
+ * random draw (the prologue's) has been consumed and nothing is pending in the
+ * deposition accumulator (every facet flushes it, omp3/neutral.c:325-327). */
+template <bool kSameTables, typename IndexPtr>
+__device__ __forceinline__ void resume(History& h, const SolveArgs& a,
+                                       const CsLookup<IndexPtr>& ix, int pid) {
+  h.dt_to_census = a.p.dt_to_census[pid];
+  h.mfp_to_collision = a.p.mfp_to_collision[pid];
+  h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
+                              (h.cellx - a.x_off + a.pad)];
+  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_density(h);
+  h.speed = speed_of(h.energy);
+  h.energy_deposition = 0.0;
+  h.counter = 1;
+}
+
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
   if (!(h.dt_to_census > 0.0)) {
@@ -169,9 +219,9 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables, typename IndexPtr>
+template <bool kSameTables, typename IndexPtr, typename Tally>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
-                                        const CsLookup<IndexPtr>& ix) {
+                                        const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
   h.energy_deposition +=
       calculate_energy_deposition(h.energy, h.weight, distance_to_collision, h.number_density,
@@ -188,7 +238,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
     h.weight *= (1.0 - p_absorb);
     if (h.energy < kMinEnergyOfInterest) {
       h.dead = 1;
-      update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+      tally(a, h.cellx, h.celly, h.energy_deposition);
       h.energy_deposition = 0.0;
       return true;
     }
@@ -219,14 +269,15 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
 }
 
 /* facet_event, omp3/neutral.c:303-380 */
-__device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a) {
+template <typename Tally>
+__device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
   const double distance_to_facet = h.distance;
   h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
   h.dt_to_census -= (distance_to_facet / h.speed);
   h.energy_deposition +=
       calculate_energy_deposition(h.energy, h.weight, distance_to_facet, h.number_density,
                                   h.micro_a, h.micro_s + h.micro_a);
-  update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+  tally(a, h.cellx, h.celly, h.energy_deposition);
   h.energy_deposition = 0.0;
 
   h.x += distance_to_facet * h.omega_x;
@@ -268,7 +319,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a) {
 }
 
 /* census_event, omp3/neutral.c:383-405 */
-__device__ __forceinline__ void census(History& h, const SolveArgs& a) {
+template <typename Tally>
+__device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tally& tally) {
   const double distance_to_census = h.distance;
   h.x += distance_to_census * h.omega_x;
   h.y += distance_to_census * h.omega_y;
@@ -276,7 +328,7 @@ __device__ __forceinline__ void census(History& h, const SolveArgs& a) {
   h.energy_deposition +=
       calculate_energy_deposition(h.energy, h.weight, distance_to_census, h.number_density,
                                   h.micro_a, h.micro_s + h.micro_a);
-  update_tallies(a, h.cellx, h.celly, h.energy_deposition);
+  tally(a, h.cellx, h.celly, h.energy_deposition);
   h.dt_to_census = 0.0;
 }
 

@@ -91,11 +91,31 @@ struct SolveArgs {
   int index_shift;
   double* tally;
   StepCounters* counters;
+  /* optional work list for the regroup kernel: ids of particles another kernel
+   * suspended at their first collision (null: all particles 0..nparticles-1) */
+  const unsigned* queue;
+  const unsigned* queue_len; /* [device] number of valid entries */
+};
+
+/* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
+struct TiledArgs {
+  unsigned* order;         /* nparticles: live particle ids sorted by tile */
+  unsigned* tile_count;    /* ntiles */
+  unsigned* tile_offset;   /* ntiles */
+  unsigned* tile_cursor;   /* ntiles */
+  uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
+  unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
+  unsigned* ctrl;          /* 4 words: chunk head, #chunks, queue length, #live */
+  int tiles_x;
+  int tiles_y;
+  int ntiles;
+  int max_chunks;
 };
 
 enum Variant {
   kVariantOverParticle = 0, /* K1: one lane owns one history start to finish */
   kVariantEventSorted = 1,  /* K2: lanes re-grouped by next event */
+  kVariantTiled = 2,        /* K3: tile-sorted streaming with an LDS tally window, then K2 */
 };
 
 hipError_t launch_inject(const InjectArgs& a, hipStream_t stream);
@@ -104,6 +124,11 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
 hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
                                const double* vb, int n, int* d_flag, hipStream_t stream);
 
+
+/* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
+size_t tiled_lds_bytes(const SolveArgs& a);
+void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
+hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

@@ -22,6 +22,7 @@
 
 #include "neutral_device.h"
 #include "neutral_history.h"
+#include "neutral_wave.h"
 
 namespace neutral {
 
@@ -35,16 +36,6 @@ constexpr int kBlock = 256;
 #ifndef NEUTRAL_K2_WAVES
 #define NEUTRAL_K2_WAVES 4
 #endif
-
-/* ---- small wave utilities -------------------------------------------------- */
-
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    v += __shfl_down(v, off, 64);
-  }
-  return v; /* valid in lane 0 */
-}
 
 /* ---- K0: injection --------------------------------------------------------- */
 
@@ -103,23 +94,6 @@ __global__ __launch_bounds__(kBlock) void inject_kernel(InjectArgs a) {
 
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
-/* one atomic per wave and counter (the cuda analog's block tree reduction +
- * host finish, cuda/neutral.k:475-493, collapsed into wave reductions) */
-__device__ __forceinline__ void flush_counters(const SolveArgs& a, unsigned nprocessed,
-                                               unsigned nfacets, unsigned ncollisions,
-                                               unsigned ncensus) {
-  const unsigned wf = wave_sum_u32(nfacets);
-  const unsigned wc = wave_sum_u32(ncollisions);
-  const unsigned wp = wave_sum_u32(nprocessed);
-  const unsigned wz = wave_sum_u32(ncensus);
-  if ((threadIdx.x & 63) == 0) {
-    if (wp) atomicAdd(&a.counters->nprocessed, (unsigned long long)wp);
-    if (wf) atomicAdd(&a.counters->nfacets, (unsigned long long)wf);
-    if (wc) atomicAdd(&a.counters->ncollisions, (unsigned long long)wc);
-    if (wz) atomicAdd(&a.counters->ncensus, (unsigned long long)wz);
-  }
-}
-
 template <bool kSameTables>
 __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(SolveArgs a) {
   const int pid = blockIdx.x * kBlock + threadIdx.x;
@@ -132,6 +106,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
   if (pid < a.nparticles && !a.p.dead[pid]) { /* omp3/neutral.c:91-93 */
     nprocessed = 1;
     const CsLookup<const unsigned short*> ix{a.scatter_index, a.absorb_index};
+    const GlobalTally tally;
     History h;
     load_particle(h, a, pid);
     prologue<kSameTables>(h, a, ix);
@@ -139,16 +114,16 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
       decide(h, a);
       if (h.ev == kEvCollision) {
         ncollisions++;
-        if (collide<kSameTables>(h, a, ix)) {
+        if (collide<kSameTables>(h, a, ix, tally)) {
           break;
         }
       } else if (h.ev == kEvFacet) {
         nfacets++;
-        cross_facet(h, a);
+        cross_facet(h, a, tally);
       } else {
         if (h.ev == kEvCensus) {
           ncensus = 1;
-          census(h, a);
+          census(h, a, tally);
         }
         break;
       }
@@ -196,12 +171,6 @@ constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many 
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
-__device__ __forceinline__ int lane_rank(unsigned long long mask) {
-  /* number of set bits of mask below this lane */
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                   __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-
 template <bool kSameTables>
 __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
@@ -229,6 +198,10 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
     }
     __syncthreads();
   }
+
+  const GlobalTally tally;
+  /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
+  const int nwork = a.queue ? (int)*a.queue_len : a.nparticles;
 
   History h;
   int pid = -1;
@@ -277,12 +250,12 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
         }
         base = __builtin_amdgcn_readfirstlane(base);
         /* the head can overshoot nparticles by at most (#waves * chunk) */
-        if (base >= a.nparticles || base < 0) {
+        if (base >= nwork || base < 0) {
           drained = true;
           cur = end = 0;
         } else {
           cur = base;
-          end = (base + kQueueChunk < a.nparticles) ? base + kQueueChunk : a.nparticles;
+          end = (base + kQueueChunk < nwork) ? base + kQueueChunk : nwork;
         }
       }
       if (!drained) {
@@ -290,11 +263,16 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
         const bool take = (want == kWantRefill) && (mine < end);
         const int avail = end - cur;
         cur += (n_refill < avail) ? n_refill : avail;
-        if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
-          pid = mine;
-          nprocessed++;
+        const int cand = take ? (a.queue ? (int)a.queue[mine] : mine) : 0;
+        if (take && !a.p.dead[cand]) { /* omp3/neutral.c:91-93 */
+          pid = cand;
           load_particle(h, a, pid);
-          prologue<kSameTables>(h, a, ix);
+          if (a.queue) {
+            resume<kSameTables>(h, a, ix, pid); /* counted as processed by the suspender */
+          } else {
+            nprocessed++;
+            prologue<kSameTables>(h, a, ix);
+          }
           decide(h, a);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
@@ -303,7 +281,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       /* ---- COLLIDE pass ---- */
       if (want == kWantCollide) {
         ncollisions++;
-        if (collide<kSameTables>(h, a, ix)) {
+        if (collide<kSameTables>(h, a, ix, tally)) {
           store_particle(h, a, pid);
           want = kWantRefill;
         } else {
@@ -316,13 +294,13 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       if (want == kWantStream) {
         if (h.ev == kEvFacet) {
           nfacets++;
-          cross_facet(h, a);
+          cross_facet(h, a, tally);
           decide(h, a);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         } else {
           if (h.ev == kEvCensus) {
             ncensus++;
-            census(h, a);
+            census(h, a, tally);
           }
           store_particle(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
@@ -486,10 +464,12 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
   if (a.nparticles <= 0) {
     return hipSuccess;
   }
-  if (variant == kVariantEventSorted) {
+  if (variant == kVariantEventSorted || a.queue) {
     /* persistent waves: as many workgroups as stay resident, never more than
      * there are chunks of work; no workgroup depends on another, so an
      * over-estimate only queues the surplus */
+    /* with a device-side queue the length is not known on the host: size for
+     * the worst case, surplus waves drain at their first refill */
     const int chunks = (a.nparticles + kQueueChunk - 1) / kQueueChunk;
     const int want_blocks = (chunks + (kBlock / 64) - 1) / (kBlock / 64);
     int grid = a.same_tables ? resident_blocks(history_regroup_kernel<true>)

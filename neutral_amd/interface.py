@@ -38,6 +38,7 @@ _u64p = C.POINTER(C.c_uint64)
 
 VARIANT_OVER_PARTICLE = 0
 VARIANT_EVENT_SORTED = 1
+VARIANT_TILED = 2
 
 F64_FIELDS = ("x", "y", "omega_x", "omega_y", "energy", "weight", "dt_to_census",
               "mfp_to_collision")

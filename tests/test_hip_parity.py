@@ -26,10 +26,18 @@ STATE_TOL = 1e-9
 
 
 @pytest.fixture(scope="module")
-def iface():
+def _iface_module():
     from neutral_amd import interface
     interface.set_quiet(True)
     return interface
+
+
+@pytest.fixture()
+def iface(_iface_module):
+    # the kernel variant is process-global state of the library: every test
+    # starts from the default (over-particle) unless it asks for another one
+    _iface_module.set_variant(_iface_module.VARIANT_OVER_PARTICLE)
+    return _iface_module
 
 
 def _rel(a, b):
@@ -176,7 +184,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("deck,nx,n,its,dt", CASES)
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_history_matches_oracle(iface, make_problem, cs, deck, nx, n, its, dt, variant):
     kw = dict(nx=nx, nparticles=n, iterations=its)
     if dt is not None:
@@ -207,11 +215,12 @@ def test_history_matches_oracle(iface, make_problem, cs, deck, nx, n, its, dt, v
     sim.close()
 
 
-def test_distinct_tables_take_the_two_search_path(iface, make_problem, cs):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_distinct_tables_take_the_two_search_path(iface, make_problem, cs, variant):
     keys, values = cs
     absorb = (keys.copy(), values * 0.5)
     prob = make_problem("csp", nx=64, nparticles=8192, iterations=2, dt=2.0e-6)
-    sim = iface.Simulation(prob, keys, values, cs_absorb=absorb)
+    sim = iface.Simulation(prob, keys, values, cs_absorb=absorb, variant=variant)
     ref = ob.OracleRun(prob, keys, values, cs_absorb=absorb)
     sim.inject()
     ref.inject()
@@ -380,12 +389,12 @@ def test_stream_tally_is_intensive_in_particle_count(iface, make_problem, cs):
     assert totals[0] == pytest.approx(totals[1], rel=2e-3)
 
 
-def test_event_regrouped_variant_is_bitwise_identical_to_over_particle(iface, make_problem, cs):
+def test_kernel_variants_are_bitwise_identical_in_particle_state(iface, make_problem, cs):
     """K2 runs the same event bodies with the same RNG counters as K1, so particle
     end states agree bit for bit; tallies differ only by summation order."""
     prob = make_problem("csp", nx=100, nparticles=50000, iterations=3, dt=1.0e-6)
     out = []
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         sim = iface.Simulation(prob, *cs, variant=variant)
         sim.inject()
         ev = [sim.step(tt) for tt in (1, 2, 3)]
@@ -393,8 +402,9 @@ def test_event_regrouped_variant_is_bitwise_identical_to_over_particle(iface, ma
         out.append((sim.particle_arrays(), sim.tally_host(),
                     [(r.nprocessed, r.facets, r.collisions, r.census) for r in ev]))
         sim.close()
-    (p0, t0, e0), (p1, t1, e1) = out
-    assert e0 == e1
-    for f in p0:
-        assert np.array_equal(p0[f], p1[f]), f
-    assert np.linalg.norm(t0 - t1) / np.linalg.norm(t0) < 1e-13
+    p0, t0, e0 = out[0]
+    for p1, t1, e1 in out[1:]:
+        assert e0 == e1
+        for f in p0:
+            assert np.array_equal(p0[f], p1[f]), f
+        assert np.linalg.norm(t0 - t1) / np.linalg.norm(t0) < 1e-13
