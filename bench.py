@@ -8,8 +8,8 @@ deck runs 10 of them).  With N GPUs the 1e8 particles are split into N
 contiguous id ranges (strong scaling), each rank tallies privately and the
 400x400 f64 tally is all-reduced (RCCL) at the end of every step.
 
-Timed region: W warm-up timesteps on a separate small particle set, then fresh
-injection, then exactly K timesteps (master_key 1..K) between barrier +
+Timed region: W untimed warm-up timesteps, then the particles are re-injected
+and the tally zeroed, then exactly K timesteps (master_key 1..K) between barrier +
 torch.cuda.synchronize() pairs; MAX over ranks.  Inputs are resident in HBM
 before the timed region starts.
 
@@ -44,16 +44,57 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(histories, facets, collisions, census, same_tables):
-    """Global-memory bytes the algorithm must touch for one launch (SURVEY.md
-    8(d)): per history 152 B of particle state in+out, 8 B density and one pair
-    of cs lookups; per event 32 B of edges; per collision one more pair of
-    lookups; per facet 16 B tally RMW + 8 B density; per census 16 B tally RMW.
-    A pair of lookups is 15 probes x 16 B + 16 B of values per table = 512 B,
-    or 272 B when both tables are the same data and the search is shared."""
+    """Global-memory bytes the algorithm must touch: per history
+    152 B of particle state in+out, 8 B density and one pair of cs lookups; per
+    event 32 B of edges; per collision one more pair of lookups; per facet 16 B
+    tally RMW + 8 B density; per census 16 B tally RMW.  A pair of lookups is
+    15 probes x 16 B + 16 B of values per table = 512 B, or 272 B when both
+    tables are the same data and the search is shared."""
     pair = 272 if same_tables else 512
     events = facets + collisions + census
     return (histories * (152 + 8 + pair) + events * 32 + collisions * pair +
             facets * 24 + census * 16)
+
+
+def kernel_rooflines(results, same_tables):
+    """Per-kernel (name, mean ms per launch, mean algorithmic bytes per launch)
+    over the timed launches of this rank.  The tiled variant has two history
+    kernels: the streaming kernel handles every history's prologue, its facets
+    and census; the collision kernel resumes the suspended histories."""
+    n = len(results)
+    if results[0].stats.variant != 2:
+        b = sum(algorithmic_bytes(r.nprocessed, r.facets, r.collisions, r.census, same_tables)
+                for r in results) / n
+        name = "history_kernel" if results[0].stats.variant == 0 else "history_regroup_kernel"
+        return [(name, sum(r.kernel_ms for r in results) / n, b)]
+    bs = bc = 0.0
+    for r in results:
+        st = r.stats
+        bs += algorithmic_bytes(r.nprocessed, st.stream_facets, 0, st.stream_census, same_tables)
+        bc += algorithmic_bytes(st.suspended, r.facets - st.stream_facets, r.collisions,
+                                r.census - st.stream_census, same_tables)
+    return [("stream_kernel", sum(r.stats.stream_ms for r in results) / n, bs / n),
+            ("history_regroup_kernel", sum(r.stats.collide_ms for r in results) / n, bc / n),
+            ("tile sort (rocPRIM radix sort + 3 small kernels)",
+             sum(r.stats.sort_ms for r in results) / n, 0.0)]
+
+
+def measured_traffic(deck, nx, ntotal, variant, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None when no
+    profile of this exact configuration is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    for e in table.get("entries", []):
+        if (e["deck"], e["nx"], e["nparticles"], e["variant"], e["kernel"]) == \
+                (deck, nx, ntotal, variant, kernel):
+            return e["hbm_bytes_per_launch"]
+    return None
 
 
 def parse_args():
@@ -65,7 +106,8 @@ def parse_args():
     ap.add_argument("--nparticles", type=int, default=None,
                     help="override the workload's total particle count")
     ap.add_argument("--nx", type=int, default=None)
-    ap.add_argument("--variant", type=int, default=None, help="0 over-particle, 1 event-sorted")
+    ap.add_argument("--variant", type=int, default=2,
+                    help="0 over-particle, 1 event-regrouped, 2 tiled (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work of the cpu_baseline sample")
@@ -191,11 +233,11 @@ def main():
         particle_steps = facets + collisions + census
 
         if rank == 0:
-            # roofline of the dominant kernel (history kernel), this rank's launches
-            kernel_s = [r.kernel_ms * 1e-3 for r in results]
-            rbytes = [algorithmic_bytes(r.nprocessed, r.facets, r.collisions, r.census,
-                                        bool(stats.same_tables)) for r in results]
-            achieved = (sum(rbytes) / len(rbytes)) / (sum(kernel_s) / len(kernel_s)) / 1e9
+            # roofline of the dominant kernel, from this rank's launches (HIP events
+            # recorded inside the C-ABI on the stream the kernels run on)
+            kernels = kernel_rooflines(results, bool(stats.same_tables))
+            dom = max(kernels, key=lambda k: k[1])
+            achieved = dom[2] / (dom[1] * 1e-3) / 1e9
             out = {
                 "metric": "particle-steps/sec",
                 "value": particle_steps / elapsed,
@@ -220,10 +262,13 @@ def main():
                            "histories": histories},
                 "global_tally": float(global_tally.sum().item()),
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "history_kernel",
-                             "kernel_ms_avg": 1e3 * sum(kernel_s) / len(kernel_s),
-                             "algorithmic_bytes_per_launch": sum(rbytes) / len(rbytes)},
+                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": measured_traffic(deck, nx, ntotal, int(stats.variant),
+                                                         dom[0]),
+                             "kernel": dom[0], "kernel_ms_avg": dom[1],
+                             "algorithmic_bytes_per_launch": dom[2]},
+                "kernels": [{"name": k[0], "ms_per_launch": k[1],
+                             "algorithmic_bytes_per_launch": k[2]} for k in kernels],
             }
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(deck, nx, K, args.cpu_seconds, tmp)

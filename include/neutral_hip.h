@@ -139,10 +139,11 @@ void move_host_buffer_to_device(const size_t len, double** src, double** dst);
 /* ---- 3. extensions (no reference counterpart) -------------------------------- */
 
 enum {
-  NEUTRAL_HIP_VARIANT_OVER_PARTICLE = 0, /* one lane owns a history (default) */
+  NEUTRAL_HIP_VARIANT_OVER_PARTICLE = 0, /* one lane owns a history */
   NEUTRAL_HIP_VARIANT_EVENT_SORTED = 1,  /* lanes regrouped by next event */
   NEUTRAL_HIP_VARIANT_TILED = 2          /* tile-sorted streaming with the tally tile in
-                                            LDS, then the event-regrouped collision kernel */
+                                            LDS, then the event-regrouped collision kernel
+                                            (default) */
 };
 
 typedef struct {
@@ -153,6 +154,15 @@ typedef struct {
   double kernel_ms;     /* HIP-event time of the step's kernels on their stream */
   int same_tables;      /* 1 when both cs tables held identical data */
   int variant;          /* kernel variant that ran */
+  /* tiled variant only (0 otherwise): HIP-event time of its three stages, the
+   * events the streaming kernel handled, and the histories it handed to the
+   * collision kernel */
+  double sort_ms;
+  double stream_ms;
+  double collide_ms;
+  uint64_t stream_facets;
+  uint64_t stream_census;
+  uint64_t suspended;
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

@@ -46,11 +46,11 @@ constexpr int kMaxIndexBuckets = 16384; /* u16 entries: 32 KB of LDS at most */
 struct State {
   hipStream_t stream = nullptr;
   uint64_t pid_base = 0;
-  int variant = NEUTRAL_HIP_VARIANT_OVER_PARTICLE;
+  int variant = NEUTRAL_HIP_VARIANT_TILED; /* fastest on every BASELINE deck (profiles/) */
   bool variant_from_env_done = false;
   int quiet = 0;
   char tests_file[NEUTRAL_MAX_STR_LEN] = "problems/neutral.tests"; /* neutral_data.h:33 */
-  NeutralHipStepStats last = {0, 0, 0, 0, 0.0, 0, 0};
+  NeutralHipStepStats last = {};
   /* per-device scratch, created on first use */
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
@@ -58,6 +58,8 @@ struct State {
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   hipEvent_t ev_start = nullptr;
   hipEvent_t ev_stop = nullptr;
+  hipEvent_t ev_sorted = nullptr;   /* tiled variant: after the sort */
+  hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   /* workspace of the tiled variant, grown on demand */
   neutral::TiledArgs tiled = {};
   int tiled_particles = 0;
@@ -74,13 +76,15 @@ void ensure_scratch() {
     return;
   }
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
-  HIP_CHECK(hipMalloc((void**)&g.d_counters, sizeof(neutral::StepCounters)));
+  HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
   HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
   for (unsigned short*& d : g.d_index) {
     HIP_CHECK(hipMalloc((void**)&d, sizeof(unsigned short) * (kMaxIndexBuckets + 1)));
   }
   HIP_CHECK(hipEventCreate(&g.ev_start));
   HIP_CHECK(hipEventCreate(&g.ev_stop));
+  HIP_CHECK(hipEventCreate(&g.ev_sorted));
+  HIP_CHECK(hipEventCreate(&g.ev_streamed));
   g.scratch_device = dev;
 }
 
@@ -147,20 +151,20 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   int tx, ty, max_chunks;
   neutral::tiled_geometry(nx, ny, nparticles, &tx, &ty, &max_chunks);
   neutral::TiledArgs& t = g.tiled;
-  if (nparticles > g.tiled_particles) {
-    if (t.order) HIP_CHECK(hipFree(t.order));
-    if (t.collide_queue) HIP_CHECK(hipFree(t.collide_queue));
-    HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * (size_t)nparticles));
-    HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * (size_t)nparticles));
+  if (nparticles > g.tiled_particles || tx * ty > g.tiled_tiles) {
+    void* old[] = {t.order, t.collide_queue, t.keys_in, t.keys_out, t.sort_temp, t.tile_offset};
+    for (void* p : old) {
+      if (p) HIP_CHECK(hipFree(p));
+    }
+    const size_t n = (size_t)nparticles;
+    HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.keys_in, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.keys_out, sizeof(unsigned) * n));
+    t.sort_temp_bytes = neutral::tiled_sort_temp_bytes(nparticles, tx * ty);
+    HIP_CHECK(hipMalloc(&t.sort_temp, t.sort_temp_bytes ? t.sort_temp_bytes : 16));
+    HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty + 2)));
     g.tiled_particles = nparticles;
-  }
-  if (tx * ty > g.tiled_tiles) {
-    if (t.tile_count) HIP_CHECK(hipFree(t.tile_count));
-    if (t.tile_offset) HIP_CHECK(hipFree(t.tile_offset));
-    if (t.tile_cursor) HIP_CHECK(hipFree(t.tile_cursor));
-    HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * (size_t)(tx * ty)));
-    HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty)));
-    HIP_CHECK(hipMalloc((void**)&t.tile_cursor, sizeof(unsigned) * (size_t)(tx * ty)));
     g.tiled_tiles = tx * ty;
   }
   if (max_chunks > g.tiled_chunks) {
@@ -329,7 +333,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.queue = nullptr;
   a.queue_len = nullptr;
 
-  HIP_CHECK(hipMemsetAsync(g.d_counters, 0, sizeof(neutral::StepCounters), g.stream));
+  HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
   const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
   if (tiled) {
     if (pad != 0) {
@@ -349,17 +353,34 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
   HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
   if (tiled) {
-    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream));
+    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, g.ev_sorted, g.ev_streamed));
   } else {
     HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
   }
   HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
 
-  neutral::StepCounters h;
-  HIP_CHECK(hipMemcpyAsync(&h, g.d_counters, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+  neutral::StepCounters hc[2];
+  HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
+  unsigned queue_len = 0;
+  if (tiled) {
+    HIP_CHECK(hipMemcpyAsync(&queue_len, &g.tiled.ctrl[2], sizeof(unsigned),
+                             hipMemcpyDeviceToHost, g.stream));
+  }
   HIP_CHECK(hipStreamSynchronize(g.stream));
   float ms = 0.0f;
   HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
+  float ms_sort = 0.0f, ms_stream = 0.0f, ms_collide = ms;
+  if (tiled) {
+    HIP_CHECK(hipEventElapsedTime(&ms_sort, g.ev_start, g.ev_sorted));
+    HIP_CHECK(hipEventElapsedTime(&ms_stream, g.ev_sorted, g.ev_streamed));
+    HIP_CHECK(hipEventElapsedTime(&ms_collide, g.ev_streamed, g.ev_stop));
+  }
+
+  neutral::StepCounters h = hc[0];
+  h.nprocessed += hc[1].nprocessed;
+  h.nfacets += hc[1].nfacets;
+  h.ncollisions += hc[1].ncollisions;
+  h.ncensus += hc[1].ncensus;
 
   *facet_events += h.nfacets; /* omp3/neutral.c:202-203 */
   *collision_events += h.ncollisions;
@@ -371,6 +392,12 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.kernel_ms = (double)ms;
   g.last.same_tables = same;
   g.last.variant = g.variant;
+  g.last.sort_ms = (double)ms_sort;
+  g.last.stream_ms = (double)ms_stream;
+  g.last.collide_ms = (double)ms_collide;
+  g.last.stream_facets = tiled ? hc[0].nfacets : 0;
+  g.last.stream_census = tiled ? hc[0].ncensus : 0;
+  g.last.suspended = queue_len;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

@@ -76,6 +76,10 @@ struct WindowTally {
     const unsigned lx = (unsigned)(cellx - ox);
     const unsigned ly = (unsigned)(celly - oy);
     const double v = energy_deposition * a.inv_ntotal_particles;
+#if defined(NEUTRAL_EXP_NO_TALLY)
+    if (v == 1.2345e300) window[0] = v; /* timing experiment only */
+    return;
+#endif
     if (lx < (unsigned)W && ly < (unsigned)W) {
       /* ds_add_f64, no return value */
       (void)__hip_atomic_fetch_add(&window[ly * W + lx], v, __ATOMIC_RELAXED,

@@ -99,10 +99,12 @@ struct SolveArgs {
 
 /* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
 struct TiledArgs {
-  unsigned* order;         /* nparticles: live particle ids sorted by tile */
-  unsigned* tile_count;    /* ntiles */
-  unsigned* tile_offset;   /* ntiles */
-  unsigned* tile_cursor;   /* ntiles */
+  unsigned* order;         /* nparticles: particle ids sorted by tile (dead ones last) */
+  unsigned* keys_in;       /* nparticles: tile of each particle, ntiles when dead */
+  unsigned* keys_out;      /* nparticles: sorted keys */
+  void* sort_temp;         /* rocPRIM radix sort scratch */
+  size_t sort_temp_bytes;
+  unsigned* tile_offset;   /* ntiles + 2: first sorted position of each key */
   uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   unsigned* ctrl;          /* 4 words: chunk head, #chunks, queue length, #live */
@@ -127,8 +129,13 @@ hipError_t launch_tables_equal(const double* ka, const double* va, const double*
 
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
 size_t tiled_lds_bytes(const SolveArgs& a);
+size_t tiled_sort_temp_bytes(int nparticles, int ntiles);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
-hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream);
+/* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
+ * collision kernel.  The optional events are recorded after the sort and after
+ * the streaming kernel. */
+hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream,
+                              hipEvent_t after_sort, hipEvent_t after_stream);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

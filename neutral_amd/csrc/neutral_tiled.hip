@@ -9,10 +9,11 @@
  * a 400^2 f64 tally (1.28 MB) does not fit 160 KB of LDS -- a window of it does,
  * if the particles a workgroup works on are spatially close.  So, per timestep:
  *
- *   1. tile_count / tile_scan / tile_scatter   counting sort of the LIVE
- *      particle ids by the 16x16-cell tile they start the step in (dead
- *      particles drop out of the work list here instead of being re-scanned
- *      every step, omp3/neutral.c:91-93);
+ *   1. tile_key / radix sort / tile_bounds / tile_chunks   the LIVE particle ids
+ *      sorted by the 16x16-cell tile they start the step in (rocPRIM radix sort
+ *      over the log2(#tiles) key bits; dead particles get the largest key and
+ *      drop out of the work list instead of being re-scanned every step,
+ *      omp3/neutral.c:91-93);
  *   2. stream_kernel   1024-thread persistent workgroups take chunks of one
  *      tile's particles.  A 128x128-cell f64 window of the tally centred on the
  *      tile lives in LDS (128 KB): facet and census tallies inside it are
@@ -29,6 +30,10 @@
  * in K1, so particle end states are bit-identical; only the summation order of
  * the tally changes.
  */
+#include <cstring> /* before rocprim: its texture iterator calls ::memset on the host */
+
+#include <rocprim/rocprim.hpp>
+
 #include "neutral_kernels.h"
 
 #include "neutral_device.h"
@@ -57,107 +62,70 @@ __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly)
   return (celly / kTile) * t.tiles_x + (cellx / kTile);
 }
 
-/* ---- 1. counting sort of live particle ids by tile ----------------------------- */
+/* ---- 1. sort of the live particle ids by tile ----------------------------------- */
 
-/* Adds one per lane to counter[key] for the lanes in `active`, with one atomic
- * per distinct key in the wave; returns this lane's rank among equal keys and
- * the value the counter had before the wave's add (valid for active lanes). */
-__device__ __forceinline__ unsigned wave_aggregated_add(unsigned* counter, int key, bool active,
-                                                        unsigned& rank_in_key) {
-  unsigned base = 0;
-  rank_in_key = 0;
-  unsigned long long todo = __ballot(active);
-  while (todo) { /* wave-uniform loop: one trip per distinct key */
-    const int leader = __ffsll((long long)todo) - 1;
-    const int leader_key = __shfl(key, leader, 64);
-    const unsigned long long same = __ballot(active && key == leader_key);
-    unsigned b = 0;
-    if ((int)(threadIdx.x & 63) == leader) {
-      b = atomicAdd(&counter[leader_key], (unsigned)__popcll(same));
-    }
-    b = __shfl(b, leader, 64);
-    if (active && key == leader_key) {
-      base = b;
-      rank_in_key = (unsigned)lane_rank(same);
-    }
-    todo &= ~same;
-  }
-  return base;
-}
-
-__global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, TiledArgs t) {
-  const int stride = gridDim.x * kSortBlock;
-  for (int base = blockIdx.x * kSortBlock; base < a.nparticles; base += stride) {
-    const int pid = base + threadIdx.x;
-    const bool live = pid < a.nparticles && !a.p.dead[pid];
-    const int key = live ? tile_of(t, a.p.cellx[pid] - a.x_off, a.p.celly[pid] - a.y_off) : 0;
-    unsigned rank;
-    wave_aggregated_add(t.tile_count, key, live, rank);
+/* key of every particle: its tile, or ntiles for a dead particle (sorts last) */
+__global__ __launch_bounds__(kSortBlock) void tile_key_kernel(SolveArgs a, TiledArgs t) {
+  const int pid = blockIdx.x * kSortBlock + threadIdx.x;
+  if (pid < a.nparticles) {
+    t.keys_in[pid] = a.p.dead[pid]
+                         ? (unsigned)t.ntiles
+                         : (unsigned)tile_of(t, a.p.cellx[pid] - a.x_off, a.p.celly[pid] - a.y_off);
   }
 }
 
-/* single workgroup: exclusive scan of the tile counts, then the chunk list */
-__global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
-  __shared__ unsigned s_part[1024];
+/* tile_offset[k] = first position of key k in the sorted keys, for k = 0..ntiles+1
+ * (empty tiles included): position i starts every key in (keys[i-1], keys[i]] */
+__global__ __launch_bounds__(kSortBlock) void tile_bounds_kernel(SolveArgs a, TiledArgs t) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i > a.nparticles) {
+    return;
+  }
+  const int prev = (i == 0) ? -1 : (int)t.keys_out[i - 1];
+  const int cur = (i == a.nparticles) ? t.ntiles + 1 : (int)t.keys_out[i];
+  for (int k = prev + 1; k <= cur; ++k) {
+    t.tile_offset[k] = (unsigned)i;
+  }
+}
+
+/* single workgroup: the chunk list, from the tile populations */
+__global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   __shared__ unsigned s_chunks[1024];
   const int tid = threadIdx.x;
   const int per = (t.ntiles + 1023) / 1024;
   const int lo = tid * per;
   const int hi = (lo + per < t.ntiles) ? lo + per : t.ntiles;
 
-  unsigned sum = 0;
   unsigned nch = 0;
   for (int i = lo; i < hi; ++i) {
-    const unsigned c = t.tile_count[i];
-    sum += c;
+    const unsigned c = t.tile_offset[i + 1] - t.tile_offset[i];
     nch += (c + kChunkParticles - 1) / kChunkParticles;
   }
-  s_part[tid] = sum;
   s_chunks[tid] = nch;
   __syncthreads();
-  /* Hillis-Steele inclusive scan over the 1024 partials */
-  for (int off = 1; off < 1024; off <<= 1) {
-    const unsigned a0 = (tid >= off) ? s_part[tid - off] : 0;
+  for (int off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
     const unsigned c0 = (tid >= off) ? s_chunks[tid - off] : 0;
     __syncthreads();
-    s_part[tid] += a0;
     s_chunks[tid] += c0;
     __syncthreads();
   }
-  unsigned offset = s_part[tid] - sum;   /* exclusive */
-  unsigned chunk = s_chunks[tid] - nch;
+  unsigned chunk = s_chunks[tid] - nch; /* exclusive */
   for (int i = lo; i < hi; ++i) {
-    const unsigned c = t.tile_count[i];
-    t.tile_offset[i] = offset;
-    t.tile_cursor[i] = 0;
-    for (unsigned b = 0; b < c; b += kChunkParticles) {
-      const unsigned e = (b + kChunkParticles < c) ? b + kChunkParticles : c;
+    const unsigned begin = t.tile_offset[i];
+    const unsigned end = t.tile_offset[i + 1];
+    for (unsigned b = begin; b < end; b += kChunkParticles) {
+      const unsigned e = (b + kChunkParticles < end) ? b + kChunkParticles : end;
       if (chunk < (unsigned)t.max_chunks) {
-        t.chunks[chunk] = make_uint4(offset + b, offset + e, (unsigned)i, 0u);
+        t.chunks[chunk] = make_uint4(b, e, (unsigned)i, 0u);
       }
       chunk++;
     }
-    offset += c;
   }
   if (tid == 1023) {
     t.ctrl[kCtrlNumChunks] = s_chunks[1023];
-    t.ctrl[kCtrlLive] = s_part[1023];
+    t.ctrl[kCtrlLive] = t.tile_offset[t.ntiles];
     t.ctrl[kCtrlChunkHead] = 0;
     t.ctrl[kCtrlCollideCount] = 0;
-  }
-}
-
-__global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, TiledArgs t) {
-  const int stride = gridDim.x * kSortBlock;
-  for (int base = blockIdx.x * kSortBlock; base < a.nparticles; base += stride) {
-    const int pid = base + threadIdx.x;
-    const bool live = pid < a.nparticles && !a.p.dead[pid];
-    const int key = live ? tile_of(t, a.p.cellx[pid] - a.x_off, a.p.celly[pid] - a.y_off) : 0;
-    unsigned rank;
-    const unsigned b = wave_aggregated_add(t.tile_cursor, key, live, rank);
-    if (live) {
-      t.order[t.tile_offset[key] + b + rank] = (unsigned)pid;
-    }
   }
 }
 
@@ -334,6 +302,19 @@ size_t tiled_lds_bytes(const SolveArgs& a) {
   return (lds + 15) & ~(size_t)15;
 }
 
+size_t tiled_sort_temp_bytes(int nparticles, int ntiles) {
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)ntiles) {
+    bits++;
+  }
+  size_t bytes = 0;
+  unsigned* none = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, none, none,
+                                  rocprim::counting_iterator<unsigned>(0u), none,
+                                  (size_t)nparticles, 0u, bits, (hipStream_t) nullptr);
+  return bytes;
+}
+
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks) {
   *tiles_x = (nx + kTile - 1) / kTile;
   *tiles_y = (ny + kTile - 1) / kTile;
@@ -341,21 +322,32 @@ void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, 
   *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticles + 1;
 }
 
-hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream) {
+hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream,
+                              hipEvent_t after_sort, hipEvent_t after_stream) {
   if (a.nparticles <= 0) {
     return hipSuccess;
   }
-  hipError_t err = hipMemsetAsync(t.tile_count, 0, sizeof(unsigned) * t.ntiles, stream);
+  /* 1. keys -> stable radix sort of (key, particle id) -> tile bounds -> chunks.
+   * Only the low bits that can differ are sorted. */
+  const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
+  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
+  unsigned bits = 1;
+  while ((1u << bits) <= (unsigned)t.ntiles) {
+    bits++;
+  }
+  size_t temp_bytes = t.sort_temp_bytes;
+  hipError_t err = rocprim::radix_sort_pairs(
+      t.sort_temp, temp_bytes, t.keys_in, t.keys_out, rocprim::counting_iterator<unsigned>(0u),
+      t.order, (size_t)a.nparticles, 0u, bits, stream);
   if (err != hipSuccess) {
     return err;
   }
-  int sort_grid = (a.nparticles + kSortBlock - 1) / kSortBlock;
-  if (sort_grid > 8192) {
-    sort_grid = 8192;
+  hipLaunchKernelGGL(tile_bounds_kernel, dim3((a.nparticles + 1 + kSortBlock - 1) / kSortBlock),
+                     dim3(kSortBlock), 0, stream, a, t);
+  hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
+  if (after_sort) {
+    (void)hipEventRecord(after_sort, stream);
   }
-  hipLaunchKernelGGL(tile_count_kernel, dim3(sort_grid), dim3(kSortBlock), 0, stream, a, t);
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, t);
-  hipLaunchKernelGGL(tile_scatter_kernel, dim3(sort_grid), dim3(kSortBlock), 0, stream, a, t);
 
   /* one 1024-thread workgroup per CU (the window takes most of the LDS) */
   int dev = 0;
@@ -378,8 +370,14 @@ hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_
     return err;
   }
 
-  /* 3. the suspended histories: K2 over the collision queue */
+  if (after_stream) {
+    (void)hipEventRecord(after_stream, stream);
+  }
+
+  /* 3. the suspended histories: K2 over the collision queue; it counts its
+   * events in the second StepCounters record */
   SolveArgs c = a;
+  c.counters = a.counters + 1;
   c.queue = t.collide_queue;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
   return launch_solve(c, kVariantEventSorted, stream);

@@ -59,7 +59,10 @@ class StepStats(C.Structure):
     _fields_ = [("nprocessed", C.c_uint64), ("facets", C.c_uint64),
                 ("collisions", C.c_uint64), ("census", C.c_uint64),
                 ("kernel_ms", C.c_double),
-                ("same_tables", C.c_int), ("variant", C.c_int)]
+                ("same_tables", C.c_int), ("variant", C.c_int),
+                ("sort_ms", C.c_double), ("stream_ms", C.c_double),
+                ("collide_ms", C.c_double), ("stream_facets", C.c_uint64),
+                ("stream_census", C.c_uint64), ("suspended", C.c_uint64)]
 
 
 # every symbol include/neutral_hip.h declares
@@ -244,6 +247,7 @@ class StepResult:
     collisions: int
     kernel_ms: float
     census: int = 0
+    stats: Optional["StepStats"] = None
 
     @property
     def particle_steps(self) -> int:
@@ -325,7 +329,7 @@ class Simulation:
             self.cs_absorb, self.tally.data_ptr(), None, None, None, facets, collisions)
         s = last_step()
         return StepResult(int(s.nprocessed), facets.value, collisions.value, s.kernel_ms,
-                          int(s.census))
+                          int(s.census), s)
 
     def particle_arrays(self):
         """Host copies of the SoA particle store."""
