@@ -163,11 +163,10 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
 /* ---- geometry (omp3/neutral.c:423-471) ------------------------------------- */
 
 __device__ __forceinline__ void calc_distance_to_facet(
-    double x, double y, double omega_x, double omega_y, double speed,
-    double ex_lo, double ex_hi, double ey_lo, double ey_hi,
+    double x, double y, double omega_x, double omega_y, double speed, double u_x_inv,
+    double u_y_inv, double ex_lo, double ex_hi, double ey_lo, double ey_hi,
     double& distance_to_facet, int& x_facet) {
-  const double u_x_inv = 1.0 / (omega_x * speed);
-  const double u_y_inv = 1.0 / (omega_y * speed);
+  /* u_x_inv = 1/(omega_x*speed), u_y_inv = 1/(omega_y*speed): omp3/neutral.c:435-436 */
 
   /* the bound is open on the left/bottom: aim slightly past the edge */
   const double ax = (omega_x >= 0.0) ? (ex_hi - x) : ((ex_lo - kOpenBoundCorrection) - x);

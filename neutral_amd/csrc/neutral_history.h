@@ -35,6 +35,14 @@ struct History {
   /* locals of handle_particles that live across events */
   double local_density, micro_s, micro_a, number_density, macro_s, macro_a, speed;
   double energy_deposition;
+  /* Values the reference recomputes at every event although their inputs only
+   * change at a collision, a reflection or a density change; they are
+   * recomputed here exactly when an input changes (same operations on the same
+   * operands, hence the same bits):
+   *   u_x_inv, u_y_inv   1/(omega*speed)                  omp3/neutral.c:435-436
+   *   cell_mfp           1/(macro_s+macro_a)              :135
+   *   dep_sigma/dep_heat factors of the heating estimator :481-494 */
+  double u_x_inv, u_y_inv, dep_sigma, dep_heat;
   uint64_t pkey;
   unsigned counter;
   /* the decision taken at the loop head */
@@ -126,10 +134,37 @@ __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<Ind
 }
 
 __device__ __forceinline__ void macroscopic_from_density(History& h) {
-  /* omp3/neutral.c:112-116, :289-291, :375-377 */
+  /* omp3/neutral.c:112-116, :289-291, :375-377, and the loop head's :135 */
   h.number_density = (h.local_density * kAvogadros / kMolarMass);
   h.macro_s = h.number_density * h.micro_s * kBarns;
   h.macro_a = h.number_density * h.micro_a * kBarns;
+  h.cell_mfp = 1.0 / (h.macro_s + h.macro_a);
+}
+
+/* omp3/neutral.c:435-436 */
+__device__ __forceinline__ void refresh_direction(History& h) {
+  h.u_x_inv = 1.0 / (h.omega_x * h.speed);
+  h.u_y_inv = 1.0 / (h.omega_y * h.speed);
+}
+
+/* the energy- and table-dependent factors of calculate_energy_deposition
+ * (omp3/neutral.c:481-494); deposit() below finishes the product */
+__device__ __forceinline__ void refresh_deposition_terms(History& h) {
+  const double microscopic_cs_total = h.micro_s + h.micro_a;
+  constexpr double average_exit_energy_absorb = 0.0;
+  const double absorption_heating =
+      (h.micro_a / microscopic_cs_total) * average_exit_energy_absorb;
+  const double average_exit_energy_scatter =
+      h.energy * ((kMassNo * kMassNo + kMassNo + 1) / ((kMassNo + 1) * (kMassNo + 1)));
+  const double scattering_heating =
+      (1.0 - (h.micro_a / microscopic_cs_total)) * average_exit_energy_scatter;
+  h.dep_heat = (h.energy - scattering_heating - absorption_heating);
+  h.dep_sigma = (microscopic_cs_total * kBarns);
+}
+
+/* omp3/neutral.c:493-494 */
+__device__ __forceinline__ double deposit(const History& h, double path_length) {
+  return h.weight * path_length * h.dep_sigma * h.dep_heat * h.number_density;
 }
 
 __device__ __forceinline__ void load_particle(History& h, const SolveArgs& a, int pid) {
@@ -174,6 +209,8 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   double rn0, rn1;
   generate_random_numbers(h.pkey, a.master_key, h.counter++, rn0, rn1);
   h.mfp_to_collision = -log(rn0) / h.macro_s;
+  refresh_direction(h);
+  refresh_deposition_terms(h);
 }
 
 /* Re-derives the locals of a history that another kernel suspended at a loop
@@ -194,6 +231,8 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
   h.counter = 1;
+  refresh_direction(h);
+  refresh_deposition_terms(h);
 }
 
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
@@ -202,12 +241,12 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
     h.ev = kEvEnd;
     return;
   }
-  h.cell_mfp = 1.0 / (h.macro_s + h.macro_a);
   const int ex = h.cellx - a.x_off + a.pad;
   const int ey = h.celly - a.y_off + a.pad;
   double distance_to_facet;
-  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, a.edgex[ex], a.edgex[ex + 1],
-                         a.edgey[ey], a.edgey[ey + 1], distance_to_facet, h.x_facet);
+  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
+                         a.edgex[ex], a.edgex[ex + 1], a.edgey[ey], a.edgey[ey + 1],
+                         distance_to_facet, h.x_facet);
   const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
   const double distance_to_census = h.speed * h.dt_to_census;
   if (distance_to_collision < distance_to_facet && distance_to_collision < distance_to_census) {
@@ -227,9 +266,7 @@ template <bool kSameTables, typename IndexPtr, typename Tally>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
                                         const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
-  h.energy_deposition +=
-      calculate_energy_deposition(h.energy, h.weight, distance_to_collision, h.number_density,
-                                  h.micro_a, h.micro_s + h.micro_a);
+  h.energy_deposition += deposit(h, distance_to_collision);
   h.x += distance_to_collision * h.omega_x;
   h.y += distance_to_collision * h.omega_y;
 
@@ -269,6 +306,8 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   h.mfp_to_collision = -log(rn0) / h.macro_s;
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);
+  refresh_direction(h);
+  refresh_deposition_terms(h);
   return false;
 }
 
@@ -278,9 +317,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   const double distance_to_facet = h.distance;
   h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
   h.dt_to_census -= (distance_to_facet / h.speed);
-  h.energy_deposition +=
-      calculate_energy_deposition(h.energy, h.weight, distance_to_facet, h.number_density,
-                                  h.micro_a, h.micro_s + h.micro_a);
+  h.energy_deposition += deposit(h, distance_to_facet);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   h.energy_deposition = 0.0;
 
@@ -292,12 +329,14 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     if (h.omega_x > 0.0) {
       if (h.cellx >= (a.global_nx - 1)) {
         h.omega_x = -h.omega_x;
+        h.u_x_inv = 1.0 / (h.omega_x * h.speed);
       } else {
         h.cellx++;
       }
     } else if (h.omega_x < 0.0) {
       if (h.cellx <= 0) {
         h.omega_x = -h.omega_x;
+        h.u_x_inv = 1.0 / (h.omega_x * h.speed);
       } else {
         h.cellx--;
       }
@@ -306,20 +345,25 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     if (h.omega_y > 0.0) {
       if (h.celly >= (a.global_ny - 1)) {
         h.omega_y = -h.omega_y;
+        h.u_y_inv = 1.0 / (h.omega_y * h.speed);
       } else {
         h.celly++;
       }
     } else if (h.omega_y < 0.0) {
       if (h.celly <= 0) {
         h.omega_y = -h.omega_y;
+        h.u_y_inv = 1.0 / (h.omega_y * h.speed);
       } else {
         h.celly--;
       }
     }
   }
 
-  h.local_density = a.density[(h.celly - a.y_off) * a.nx + (h.cellx - a.x_off)];
-  macroscopic_from_density(h);
+  const double new_density = a.density[(h.celly - a.y_off) * a.nx + (h.cellx - a.x_off)];
+  if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
+    h.local_density = new_density;
+    macroscopic_from_density(h);
+  }
 }
 
 /* census_event, omp3/neutral.c:383-405 */
@@ -329,9 +373,7 @@ __device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tal
   h.x += distance_to_census * h.omega_x;
   h.y += distance_to_census * h.omega_y;
   h.mfp_to_collision -= (distance_to_census / h.cell_mfp);
-  h.energy_deposition +=
-      calculate_energy_deposition(h.energy, h.weight, distance_to_census, h.number_density,
-                                  h.micro_a, h.micro_s + h.micro_a);
+  h.energy_deposition += deposit(h, distance_to_census);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   h.dt_to_census = 0.0;
 }

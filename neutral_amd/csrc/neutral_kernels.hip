@@ -397,7 +397,8 @@ __global__ __launch_bounds__(kBlock) void probe_facet_kernel(const double* in, d
     const double* r = in + 9 * i;
     double d;
     int xf;
-    calc_distance_to_facet(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], d, xf);
+    calc_distance_to_facet(r[0], r[1], r[2], r[3], r[4], 1.0 / (r[2] * r[4]), 1.0 / (r[3] * r[4]),
+                           r[5], r[6], r[7], r[8], d, xf);
     dist[i] = d;
     x_facet[i] = xf;
   }
