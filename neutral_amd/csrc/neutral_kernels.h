@@ -28,6 +28,18 @@ struct ParticleView {
   int* dead;
 };
 
+/* One particle as a record: the private working layout of the tiled variant.
+ * Sorted-by-tile access is random per particle, and a random 80-B record costs
+ * two 64-B sectors where the SoA store costs eleven; the records are kept in
+ * tile order from step to step and carry the particle id (the RNG key). */
+struct alignas(16) ParticleRec {
+  double x, y, omega_x, omega_y, energy, weight, dt_to_census, mfp_to_collision;
+  int cellx, celly;
+  unsigned id; /* index in the SoA store = global id - pid_base */
+  int dead;
+};
+static_assert(sizeof(ParticleRec) == 80, "ParticleRec must stay 80 bytes");
+
 struct InjectArgs {
   int nparticles;
   uint64_t pid_base;
@@ -95,11 +107,14 @@ struct SolveArgs {
    * suspended at their first collision (null: all particles 0..nparticles-1) */
   const unsigned* queue;
   const unsigned* queue_len; /* [device] number of valid entries */
+  ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
 };
 
 /* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
 struct TiledArgs {
-  unsigned* order;         /* nparticles: particle ids sorted by tile (dead ones last) */
+  ParticleRec* rec_in;     /* nparticles: records in last step's order */
+  ParticleRec* rec_out;    /* nparticles: records in this step's tile order */
+  unsigned* order;         /* nparticles: rec_in indices sorted by tile (dead ones last) */
   unsigned* keys_in;       /* nparticles: tile of each particle, ntiles when dead */
   unsigned* keys_out;      /* nparticles: sorted keys */
   void* sort_temp;         /* rocPRIM radix sort scratch */
@@ -130,6 +145,10 @@ hipError_t launch_tables_equal(const double* ka, const double* va, const double*
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
 size_t tiled_lds_bytes(const SolveArgs& a);
 size_t tiled_sort_temp_bytes(int nparticles, int ntiles);
+/* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
+hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, int n, hipStream_t stream);
+hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, int n,
+                                 hipStream_t stream);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
 /* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
  * collision kernel.  The optional events are recorded after the sort and after

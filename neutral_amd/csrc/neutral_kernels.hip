@@ -171,6 +171,15 @@ constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many 
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
+/* final state of a history: into the SoA store, or into its record in queue mode */
+__device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
+  if (a.queue) {
+    store_record(h, a, a.rec[pid]);
+  } else {
+    store_particle(h, a, pid);
+  }
+}
+
 template <bool kSameTables>
 __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
@@ -260,19 +269,25 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       }
       if (!drained) {
         const int mine = cur + lane_rank(m_refill);
-        const bool take = (want == kWantRefill) && (mine < end);
+        bool take = (want == kWantRefill) && (mine < end);
         const int avail = end - cur;
         cur += (n_refill < avail) ? n_refill : avail;
-        const int cand = take ? (a.queue ? (int)a.queue[mine] : mine) : 0;
-        if (take && !a.p.dead[cand]) { /* omp3/neutral.c:91-93 */
-          pid = cand;
-          load_particle(h, a, pid);
-          if (a.queue) {
-            resume<kSameTables>(h, a, ix, pid); /* counted as processed by the suspender */
-          } else {
-            nprocessed++;
-            prologue<kSameTables>(h, a, ix);
+        if (a.queue) {
+          /* a history the streaming kernel suspended: its record is the state */
+          if (take) {
+            pid = (int)a.queue[mine];
+            load_record(h, a, a.rec[pid]);
+            resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
           }
+        } else if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
+          pid = mine;
+          nprocessed++;
+          load_particle(h, a, pid);
+          prologue<kSameTables>(h, a, ix);
+        } else {
+          take = false;
+        }
+        if (take) {
           decide(h, a);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       if (want == kWantCollide) {
         ncollisions++;
         if (collide<kSameTables>(h, a, ix, tally)) {
-          store_particle(h, a, pid);
+          put_back(h, a, pid);
           want = kWantRefill;
         } else {
           decide(h, a);
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
             ncensus++;
             census(h, a, tally);
           }
-          store_particle(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
+          put_back(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
         }
       }

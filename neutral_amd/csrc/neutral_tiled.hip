@@ -9,7 +9,10 @@
  * a 400^2 f64 tally (1.28 MB) does not fit 160 KB of LDS -- a window of it does,
  * if the particles a workgroup works on are spatially close.  So, per timestep:
  *
- *   1. tile_key / radix sort / tile_bounds / tile_chunks   the LIVE particle ids
+ *   0. the variant works on a private array of 80-byte particle RECORDS kept in
+ *      tile order from step to step (neutral_kernels.h: ParticleRec); the SoA
+ *      store of the interface is imported once and exported on demand;
+ *   1. tile_key / radix sort / tile_bounds / tile_chunks   the LIVE records
  *      sorted by the 16x16-cell tile they start the step in (rocPRIM radix sort
  *      over the log2(#tiles) key bits; dead particles get the largest key and
  *      drop out of the work list instead of being re-scanned every step,
@@ -64,13 +67,65 @@ __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly)
 
 /* ---- 1. sort of the live particle ids by tile ----------------------------------- */
 
-/* key of every particle: its tile, or ntiles for a dead particle (sorts last) */
+/* key of every record: its tile, or ntiles for a dead particle (sorts last) */
 __global__ __launch_bounds__(kSortBlock) void tile_key_kernel(SolveArgs a, TiledArgs t) {
-  const int pid = blockIdx.x * kSortBlock + threadIdx.x;
-  if (pid < a.nparticles) {
-    t.keys_in[pid] = a.p.dead[pid]
-                         ? (unsigned)t.ntiles
-                         : (unsigned)tile_of(t, a.p.cellx[pid] - a.x_off, a.p.celly[pid] - a.y_off);
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < a.nparticles) {
+    const ParticleRec& r = t.rec_in[i];
+    t.keys_in[i] = r.dead ? (unsigned)t.ntiles
+                          : (unsigned)tile_of(t, r.cellx - a.x_off, r.celly - a.y_off);
+  }
+}
+
+/* dead particles keep their record: copied behind the live ones, untouched */
+__global__ __launch_bounds__(kSortBlock) void copy_dead_kernel(SolveArgs a, TiledArgs t) {
+  const unsigned first_dead = t.tile_offset[t.ntiles];
+  const unsigned j = first_dead + blockIdx.x * kSortBlock + threadIdx.x;
+  if (j < (unsigned)a.nparticles) {
+    t.rec_out[j] = t.rec_in[t.order[j]];
+  }
+}
+
+/* SoA store -> records, in id order */
+__global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
+                                                                    int n) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < n) {
+    ParticleRec r;
+    r.x = p.x[i];
+    r.y = p.y[i];
+    r.omega_x = p.omega_x[i];
+    r.omega_y = p.omega_y[i];
+    r.energy = p.energy[i];
+    r.weight = p.weight[i];
+    r.dt_to_census = p.dt_to_census[i];
+    r.mfp_to_collision = p.mfp_to_collision[i];
+    r.cellx = p.cellx[i];
+    r.celly = p.celly[i];
+    r.id = (unsigned)i;
+    r.dead = p.dead[i];
+    rec[i] = r;
+  }
+}
+
+/* records -> SoA store, each to the slot of its id */
+__global__ __launch_bounds__(kSortBlock) void export_records_kernel(const ParticleRec* rec,
+                                                                    ParticleView p, int n) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < n) {
+    const ParticleRec r = rec[i];
+    const unsigned k = r.id;
+    p.x[k] = r.x;
+    p.y[k] = r.y;
+    p.omega_x[k] = r.omega_x;
+    p.omega_y[k] = r.omega_y;
+    p.energy[k] = r.energy;
+    p.weight[k] = r.weight;
+    p.dt_to_census[k] = r.dt_to_census;
+    p.mfp_to_collision[k] = r.mfp_to_collision;
+    p.cellx[k] = r.cellx;
+    p.celly[k] = r.celly;
+    p.dead[k] = r.dead;
   }
 }
 
@@ -241,9 +296,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         } else {
           const int mine = base + lane_rank(m_empty);
           if (!has && mine < chunk_end) {
-            pid = (int)t.order[mine];
+            pid = mine; /* this history's slot in rec_out */
             nprocessed++;
-            load_particle(h, a, pid);
+            load_record(h, a, t.rec_in[t.order[mine]]);
             prologue<kSameTables>(h, a, ix);
             decide(h, a);
             has = true;
@@ -262,7 +317,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             ncensus++;
             census(h, a, tally);
           }
-          store_particle(h, a, pid); /* kEvEnd: the loop at omp3/neutral.c:134 exits */
+          store_record(h, a, t.rec_out[pid]); /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           has = false;
         }
       }
@@ -276,7 +331,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         }
         qbase = __shfl(qbase, leader, 64);
         if (suspend) {
-          store_particle(h, a, pid);
+          store_record(h, a, t.rec_out[pid]);
           t.collide_queue[qbase + lane_rank(m_susp)] = (unsigned)pid;
           has = false;
         }
@@ -322,6 +377,24 @@ void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, 
   *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticles + 1;
 }
 
+hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, int n,
+                                 hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, p, rec, n);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, int n,
+                                 hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(export_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, rec, p, n);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream,
                               hipEvent_t after_sort, hipEvent_t after_stream) {
   if (a.nparticles <= 0) {
@@ -345,6 +418,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_
   hipLaunchKernelGGL(tile_bounds_kernel, dim3((a.nparticles + 1 + kSortBlock - 1) / kSortBlock),
                      dim3(kSortBlock), 0, stream, a, t);
   hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
+  /* (grid sized for the worst case: every particle dead) */
+  hipLaunchKernelGGL(copy_dead_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
   if (after_sort) {
     (void)hipEventRecord(after_sort, stream);
   }
@@ -379,6 +454,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_
   SolveArgs c = a;
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
+  c.rec = t.rec_out;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
   return launch_solve(c, kVariantEventSorted, stream);
 }

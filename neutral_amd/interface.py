@@ -76,6 +76,7 @@ ABI_SYMBOLS = (
     "neutral_hip_set_pid_base", "neutral_hip_get_pid_base", "neutral_hip_set_variant",
     "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
+    "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
@@ -114,6 +115,8 @@ _lib.neutral_hip_reinject_particles.argtypes = [
     C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
     C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.POINTER(Particle)]
 _lib.neutral_hip_free_particles.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_set_lazy_export.argtypes = [C.c_int]
+_lib.neutral_hip_sync_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -196,6 +199,10 @@ def set_quiet(quiet: bool) -> None:
 
 def set_tests_file(path: str) -> None:
     _lib.neutral_hip_set_tests_file(path.encode())
+
+
+def set_lazy_export(lazy: bool) -> None:
+    _lib.neutral_hip_set_lazy_export(1 if lazy else 0)
 
 
 def last_step() -> StepStats:
@@ -333,6 +340,7 @@ class Simulation:
 
     def particle_arrays(self):
         """Host copies of the SoA particle store."""
+        _lib.neutral_hip_sync_particles(self.particles)
         pc = self.particles.contents
         out = {}
         for f in F64_FIELDS:

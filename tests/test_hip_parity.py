@@ -408,3 +408,45 @@ def test_kernel_variants_are_bitwise_identical_in_particle_state(iface, make_pro
         for f in p0:
             assert np.array_equal(p0[f], p1[f]), f
         assert np.linalg.norm(t0 - t1) / np.linalg.norm(t0) < 1e-13
+
+
+def test_tiled_variant_lazy_export_and_variant_switches(iface, make_problem, cs):
+    """The tiled variant's private record store and the SoA arrays stay coherent:
+    lazy export + explicit sync, switching variants between steps, reinjection."""
+    prob = make_problem("csp", nx=100, nparticles=30000, iterations=4, dt=1.0e-6)
+    ref = iface.Simulation(prob, *cs, variant=0)
+    ref.inject()
+    for tt in (1, 2, 3, 4):
+        ref.step(tt)
+    want, t_want = ref.particle_arrays(), ref.tally_host()
+    ref.close()
+
+    iface.set_lazy_export(True)
+    try:
+        sim = iface.Simulation(prob, *cs, variant=2)
+        sim.inject()
+        sim.step(1)                      # tiled, records ahead of the SoA arrays
+        sim.step(2)                      # tiled again: records re-sorted in place
+        iface.set_variant(1)
+        sim.step(3)                      # K2 needs the SoA arrays: implicit sync
+        iface.set_variant(2)
+        sim.step(4)                      # re-import
+        got = sim.particle_arrays()      # explicit sync inside
+        for f in want:
+            assert np.array_equal(got[f], want[f]), f
+        assert np.linalg.norm(sim.tally_host() - t_want) / np.linalg.norm(t_want) < 1e-13
+        # reinjection invalidates the records
+        sim.inject()
+        sim.zero_tally()
+        r = sim.step(1)
+        ref2 = iface.Simulation(prob, *cs, variant=0)
+        ref2.inject()
+        r0 = ref2.step(1)
+        assert (r.facets, r.collisions) == (r0.facets, r0.collisions)
+        a, b = sim.particle_arrays(), ref2.particle_arrays()
+        for f in a:
+            assert np.array_equal(a[f], b[f]), f
+        sim.close()
+        ref2.close()
+    finally:
+        iface.set_lazy_export(False)

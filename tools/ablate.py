@@ -19,6 +19,7 @@ def main():
     deck, nx, n, its = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     variant = int(sys.argv[5]) if len(sys.argv) > 5 else None
     iface.set_quiet(True)
+    iface.set_lazy_export(os.environ.get("NEUTRAL_EAGER_EXPORT") != "1")
     keys, values = cs_table.load()
     with tempfile.TemporaryDirectory() as tmp:
         path = decks.write_deck(deck, os.path.join(tmp, "d.params"), nx=nx, ny=nx, nparticles=n,
