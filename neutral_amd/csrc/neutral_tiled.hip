@@ -54,7 +54,7 @@ constexpr int kStreamBlock = 1024;                 /* 16 waves share one window 
 #endif
 constexpr int kChunkParticles = NEUTRAL_CHUNK_PARTICLES;
 #ifndef NEUTRAL_STREAM_REFILL_MIN
-#define NEUTRAL_STREAM_REFILL_MIN 8
+#define NEUTRAL_STREAM_REFILL_MIN 32
 #endif
 constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
 constexpr int kSortBlock = 256;

@@ -60,3 +60,37 @@ def test_reference_driver_passes_its_own_validation_on_the_gpu(tmp_path, name):
     assert "PASSED validation." in out.stdout, out.stdout[-2000:]
     assert "File elastic_scatter.cs contains 29999 entries" in out.stdout
     shutil.rmtree(run, ignore_errors=True)
+
+
+OWN_DRIVER = os.path.join(ROOT, "neutral_amd", "host", "neutral.hip")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not gpu_available(), reason="needs a GPU")
+@pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
+def test_own_driver_runs_decks_like_the_reference_driver(tmp_path):
+    """neutral.hip (neutral_amd/host/neutral_driver.c): csp at its default size must
+    pass the reference's known answer; --set overrides give the BASELINE shapes."""
+    from neutral_amd import cs_table, decks
+    run = tmp_path / "arch" / "neutral"
+    (run / "problems").mkdir(parents=True)
+    (tmp_path / "arch" / "arch.params").write_text("width 1.0\nheight 1.0\nsim_end 100.0\n")
+    cs_table.write_files(str(run))
+    rel = os.path.join("problems", "csp.params")
+    decks.write_deck("csp", str(run / rel))
+    decks.write_tests_file(str(run / "problems" / "neutral.tests"), {"csp": rel})
+    out = subprocess.run([OWN_DRIVER, rel], cwd=str(run), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "PASSED validation." in out.stdout, out.stdout[-2000:]
+    assert out.stdout.count("Iteration") == 10
+    # BASELINE config 1 shape through --set: exact collision count of the omp3 run
+    # recorded in BASELINE.md (69 884 072 collisions, 11 facets)
+    rel2 = os.path.join("problems", "scatter.params")
+    decks.write_deck("scatter", str(run / rel2))
+    out = subprocess.run([OWN_DRIVER, rel2, "--set", "nx=100", "--set", "ny=100", "--set",
+                          "nparticles=100000", "--set", "iterations=1"], cwd=str(run),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Collisions 69884072" in out.stdout and "Facets     11" in out.stdout, out.stdout
+    assert "Particles  100000" in out.stdout

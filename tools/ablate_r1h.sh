@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { python tools/ablate.py "$@" 2>&1 | grep -v amdgpu.ids | tail -1; }
+for lib in "" chunk16384 chunk65536 chunk131072 srefill4 srefill16 srefill32; do
+  if [ -z "$lib" ]; then unset NEUTRAL_HIP_LIB; else export NEUTRAL_HIP_LIB=neutral_amd/build/libneutral_hip_$lib.so; fi
+  run csp 400 100000000 3 2
+done
