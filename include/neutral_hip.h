@@ -163,6 +163,8 @@ typedef struct {
   uint64_t stream_facets;
   uint64_t stream_census;
   uint64_t suspended;
+  int stream_passes;    /* streaming passes the step took (1 unless particles outran
+                           the LDS tally window and migrated to another tile) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

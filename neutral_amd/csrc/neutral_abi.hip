@@ -69,6 +69,13 @@ struct State {
   bool rec_valid = false;          /* records hold the current state */
   bool soa_valid = true;           /* SoA arrays hold the current state */
   int lazy_export = 0;
+  int last_passes = 0;
+  /* mesh extent: only for the tiled variant's "facets still ahead" estimate */
+  double mesh_width = 1.0;
+  double mesh_height = 1.0;
+  const void* extent_edges = nullptr;
+  int extent_nx = 0;
+  int extent_ny = 0;
   int tiled_particles = 0;
   int tiled_tiles = 0;
   int tiled_chunks = 0;
@@ -184,7 +191,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     g.tiled_chunks = max_chunks;
   }
   if (!t.ctrl) {
-    HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 4));
+    HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 8));
   }
   t.tiles_x = tx;
   t.tiles_y = ty;
@@ -397,16 +404,32 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
   HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
   if (tiled) {
-    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, g.ev_sorted, g.ev_streamed));
+    if (g.extent_edges != (const void*)edgex || g.extent_nx != nx || g.extent_ny != ny) {
+      /* mesh extent from the edge arrays (four doubles, once per mesh) */
+      double e[4];
+      HIP_CHECK(hipMemcpyAsync(&e[0], edgex + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+      HIP_CHECK(hipMemcpyAsync(&e[1], edgex + pad + nx, sizeof(double), hipMemcpyDeviceToHost,
+                               g.stream));
+      HIP_CHECK(hipMemcpyAsync(&e[2], edgey + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+      HIP_CHECK(hipMemcpyAsync(&e[3], edgey + pad + ny, sizeof(double), hipMemcpyDeviceToHost,
+                               g.stream));
+      HIP_CHECK(hipStreamSynchronize(g.stream));
+      g.mesh_width = (e[1] > e[0]) ? e[1] - e[0] : 1.0;
+      g.mesh_height = (e[3] > e[2]) ? e[3] - e[2] : 1.0;
+      g.extent_edges = (const void*)edgex;
+      g.extent_nx = nx;
+      g.extent_ny = ny;
+    }
+    g.tiled.cells_per_x = (double)nx / g.mesh_width;
+    g.tiled.cells_per_y = (double)ny / g.mesh_height;
+    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, g.ev_sorted, g.ev_streamed,
+                                          &g.last_passes));
   } else {
     HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
   }
   HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
   if (tiled) {
-    /* this step's tile order becomes next step's input order */
-    neutral::ParticleRec* tmp = g.tiled.rec_in;
-    g.tiled.rec_in = g.tiled.rec_out;
-    g.tiled.rec_out = tmp;
+    /* g.tiled.rec_in now holds this step's records, in tile order */
     g.soa_valid = false;
     if (!g.lazy_export) {
       sync_soa();
@@ -452,6 +475,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.stream_facets = tiled ? hc[0].nfacets : 0;
   g.last.stream_census = tiled ? hc[0].ncensus : 0;
   g.last.suspended = queue_len;
+  g.last.stream_passes = tiled ? g.last_passes : 0;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

@@ -77,6 +77,10 @@ struct WindowTally {
   lds_double* window; /* LDS, W*W, row-major */
   int ox;         /* local cell coordinates of window element (0,0) */
   int oy;
+  __device__ __forceinline__ bool inside(const SolveArgs& a, int pcellx, int pcelly) const {
+    return (unsigned)(pcellx - a.x_off - ox) < (unsigned)W &&
+           (unsigned)(pcelly - a.y_off - oy) < (unsigned)W;
+  }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
     const int cellx = pcellx - a.x_off;
@@ -209,8 +213,16 @@ __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, cons
   h.pkey = a.pid_base + (uint64_t)r.id;
 }
 
+/* ParticleRec::dead doubles as the record's state inside a timestep */
+enum RecState : int {
+  kRecIdle = 0,      /* alive, this step's history is complete */
+  kRecDead = 1,      /* omp3/neutral.c:91,245 */
+  kRecCollide = 2,   /* suspended at a collision, waits for the collision kernel */
+  kRecMigrate = 3,   /* left its tally window, waits for the next streaming pass */
+};
+
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
-                                             ParticleRec& r) {
+                                             ParticleRec& r, int state) {
   ParticleRec o;
   o.x = h.x;
   o.y = h.y;
@@ -223,7 +235,7 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.cellx = h.cellx;
   o.celly = h.celly;
   o.id = (unsigned)(h.pkey - a.pid_base);
-  o.dead = h.dead;
+  o.dead = state;
   r = o;
 }
 

@@ -122,7 +122,11 @@ struct TiledArgs {
   unsigned* tile_offset;   /* ntiles + 2: first sorted position of each key */
   uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
-  unsigned* ctrl;          /* 4 words: chunk head, #chunks, queue length, #live */
+  unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants */
+  int pass;                /* 0: every live record starts its history; > 0: migrants resume */
+  int allow_migrate;       /* 0 on the last permitted pass: finish with global atomics */
+  double cells_per_x;      /* nx / mesh width, ny / mesh height: for the estimate of how */
+  double cells_per_y;      /* many facets a history still has to cross */
   int tiles_x;
   int tiles_y;
   int ntiles;
@@ -151,10 +155,12 @@ hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, 
                                  hipStream_t stream);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
 /* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
- * collision kernel.  The optional events are recorded after the sort and after
- * the streaming kernel. */
-hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream);
+ * collision kernel.  The optional events are recorded after the first sort and
+ * after the last streaming pass.  Synchronises the stream once per pass (the
+ * migrant count decides whether another pass runs).  On return t.rec_in holds
+ * the records of this step (t.rec_in / t.rec_out are swapped per pass). */
+hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
+                              hipEvent_t after_sort, hipEvent_t after_stream, int* npasses);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

@@ -174,7 +174,7 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
 /* final state of a history: into the SoA store, or into its record in queue mode */
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (a.queue) {
-    store_record(h, a, a.rec[pid]);
+    store_record(h, a, a.rec[pid], h.dead ? kRecDead : kRecIdle);
   } else {
     store_particle(h, a, pid);
   }

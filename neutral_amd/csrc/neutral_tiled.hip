@@ -25,7 +25,10 @@
  *      another tile.  Lanes stream their particle (prologue, facets, census)
  *      and are refilled from the chunk like in K2.  A particle whose next event
  *      is a collision is SUSPENDED: its record is stored and its id appended to
- *      the collision queue;
+ *      the collision queue.  A particle that leaves the window with many
+ *      facets still ahead (fast particles: the stream deck crosses 553 cells per
+ *      step) is handed to the NEXT PASS of steps 1-2, which sorts the migrants by
+ *      the tile they have reached; passes repeat until nobody migrates;
  *   3. history_regroup_kernel (K2) finishes the queued histories with dense
  *      collision waves (neutral_history.h: resume()).
  *
@@ -59,7 +62,21 @@ constexpr int kChunkParticles = NEUTRAL_CHUNK_PARTICLES;
 constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
 constexpr int kSortBlock = 256;
 
-enum Ctrl : int { kCtrlChunkHead = 0, kCtrlNumChunks = 1, kCtrlCollideCount = 2, kCtrlLive = 3 };
+enum Ctrl : int {
+  kCtrlChunkHead = 0,
+  kCtrlNumChunks = 1,
+  kCtrlCollideCount = 2,
+  kCtrlActive = 3,
+  kCtrlMigrants = 4,
+};
+constexpr int kMaxStreamPasses = 64;
+/* a history leaves its window for another pass only if about this many facet
+ * crossings still lie ahead; shorter tails finish with global atomics */
+constexpr double kMigrateMinFacets = 8.0;
+/* a chunk smaller than this tallies straight to HBM: flushing a 16 384-cell
+ * window costs more than the few atomics it would save, and its particles never
+ * migrate (sparse problems degrade to the plain event-regrouped behaviour) */
+constexpr int kWindowMinParticles = 4096;
 
 __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly) {
   return (celly / kTile) * t.tiles_x + (cellx / kTile);
@@ -67,22 +84,44 @@ __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly)
 
 /* ---- 1. sort of the live particle ids by tile ----------------------------------- */
 
-/* key of every record: its tile, or ntiles for a dead particle (sorts last) */
+/* key of every record: its tile when it takes part in this pass, ntiles
+ * otherwise (sorts last).  Pass 0: every live particle; later passes: migrants. */
 __global__ __launch_bounds__(kSortBlock) void tile_key_kernel(SolveArgs a, TiledArgs t) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   if (i < a.nparticles) {
     const ParticleRec& r = t.rec_in[i];
-    t.keys_in[i] = r.dead ? (unsigned)t.ntiles
-                          : (unsigned)tile_of(t, r.cellx - a.x_off, r.celly - a.y_off);
+    const bool active = (t.pass == 0) ? (r.dead != kRecDead) : (r.dead == kRecMigrate);
+    t.keys_in[i] = active ? (unsigned)tile_of(t, r.cellx - a.x_off, r.celly - a.y_off)
+                          : (unsigned)t.ntiles;
   }
 }
 
-/* dead particles keep their record: copied behind the live ones, untouched */
-__global__ __launch_bounds__(kSortBlock) void copy_dead_kernel(SolveArgs a, TiledArgs t) {
-  const unsigned first_dead = t.tile_offset[t.ntiles];
-  const unsigned j = first_dead + blockIdx.x * kSortBlock + threadIdx.x;
+/* records that sit this pass out are carried over behind the active ones */
+__global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, TiledArgs t) {
+  const unsigned first_inactive = t.tile_offset[t.ntiles];
+  const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
   if (j < (unsigned)a.nparticles) {
     t.rec_out[j] = t.rec_in[t.order[j]];
+  }
+}
+
+/* after the last pass: the ids (positions in rec) of the histories suspended at
+ * a collision, for the collision kernel */
+__global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs a, TiledArgs t,
+                                                                       const ParticleRec* rec) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  const bool susp = i < a.nparticles && rec[i].dead == kRecCollide;
+  const unsigned long long m = __ballot(susp);
+  if (m) {
+    unsigned base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if ((int)(threadIdx.x & 63) == leader) {
+      base = atomicAdd(&t.ctrl[kCtrlCollideCount], (unsigned)__popcll(m));
+    }
+    base = __shfl(base, leader, 64);
+    if (susp) {
+      t.collide_queue[base + lane_rank(m)] = (unsigned)i;
+    }
   }
 }
 
@@ -178,9 +217,10 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   }
   if (tid == 1023) {
     t.ctrl[kCtrlNumChunks] = s_chunks[1023];
-    t.ctrl[kCtrlLive] = t.tile_offset[t.ntiles];
+    t.ctrl[kCtrlActive] = t.tile_offset[t.ntiles];
     t.ctrl[kCtrlChunkHead] = 0;
     t.ctrl[kCtrlCollideCount] = 0;
+    t.ctrl[kCtrlMigrants] = 0;
   }
 }
 
@@ -207,6 +247,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   double* window = lds_raw;                                             /* kWindow^2 f64 */
   unsigned short* lds_index = (unsigned short*)(lds_raw + kWindow * kWindow);
   __shared__ int s_chunk;
+  __shared__ int s_begin;
   __shared__ int s_end;
   __shared__ int s_tile;
   __shared__ int s_cursor;
@@ -234,12 +275,15 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   }
 
   const int nchunks = (int)t.ctrl[kCtrlNumChunks];
-  int cur_tile = -1;
+  int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
+  int win_ox = 0;
+  int win_oy = 0;
   WindowTally<kWindow> tally{(lds_double*)window, 0, 0};
 
   unsigned nfacets = 0;
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
+  unsigned nmigrants = 0;
 
   History h;
   h.ev = kEvEnd;
@@ -253,6 +297,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (c < nchunks) {
         const uint4 ch = t.chunks[c];
         s_cursor = (int)ch.x;
+        s_begin = (int)ch.x;
         s_end = (int)ch.y;
         s_tile = (int)ch.z;
       }
@@ -262,16 +307,20 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       break;
     }
     const int chunk_end = s_end;
-    if (s_tile != cur_tile) {
+    const bool windowed = (chunk_end - s_begin) >= kWindowMinParticles;
+    if (windowed && s_tile != cur_tile) {
       /* move the window: flush what the previous tile accumulated */
       if (cur_tile >= 0) {
-        flush_window(a, window, tally.ox, tally.oy);
+        flush_window(a, window, win_ox, win_oy);
       }
       cur_tile = s_tile;
-      tally.ox = (cur_tile % t.tiles_x) * kTile - kMargin;
-      tally.oy = (cur_tile / t.tiles_x) * kTile - kMargin;
+      win_ox = (cur_tile % t.tiles_x) * kTile - kMargin;
+      win_oy = (cur_tile / t.tiles_x) * kTile - kMargin;
       __syncthreads();
     }
+    /* an un-windowed chunk sees a window that contains no cell */
+    tally.ox = windowed ? win_ox : (1 << 30);
+    tally.oy = windowed ? win_oy : (1 << 30);
 
     /* ---- this wave's share of the chunk: refill / stream passes ---- */
     bool has = false;      /* lane holds a particle that wants a STREAM pass */
@@ -283,7 +332,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (n_empty + n_stream == 0) {
         break;
       }
-      bool suspend = false;
+      int park = kRecIdle; /* kRecCollide / kRecMigrate: this lane hands its history on */
       if (n_empty >= kStreamRefillMin || n_stream == 0) {
         /* REFILL: take n_empty ids of the chunk */
         int base = 0;
@@ -297,49 +346,70 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           const int mine = base + lane_rank(m_empty);
           if (!has && mine < chunk_end) {
             pid = mine; /* this history's slot in rec_out */
-            nprocessed++;
             load_record(h, a, t.rec_in[t.order[mine]]);
-            prologue<kSameTables>(h, a, ix);
+            if (t.pass == 0) {
+              nprocessed++;
+              prologue<kSameTables>(h, a, ix);
+            } else {
+              resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
+            }
             decide(h, a);
             has = true;
-            suspend = (h.ev == kEvCollision);
+            if (h.ev == kEvCollision) {
+              park = kRecCollide;
+            }
           }
         }
       } else if (has) {
         /* STREAM: one facet crossing, or the end of the history */
         if (h.ev == kEvFacet) {
-          nfacets++;
-          cross_facet(h, a, tally);
-          decide(h, a);
-          suspend = (h.ev == kEvCollision);
+          /* outside the window with a long way to go: continue in the pass that
+           * centres a window on wherever the particle is by then */
+          bool leave = false;
+          if (windowed && t.allow_migrate && !tally.inside(a, h.cellx, h.celly)) {
+            const double ahead = h.speed * h.dt_to_census;
+            const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
+                                                 fabs(h.omega_y) * t.cells_per_y);
+            leave = facets_ahead > kMigrateMinFacets;
+          }
+          if (leave) {
+            park = kRecMigrate;
+          } else {
+            nfacets++;
+            cross_facet(h, a, tally);
+            decide(h, a);
+            if (h.ev == kEvCollision) {
+              park = kRecCollide;
+            }
+          }
         } else {
           if (h.ev == kEvCensus) {
             ncensus++;
             census(h, a, tally);
           }
-          store_record(h, a, t.rec_out[pid]); /* kEvEnd: the loop at omp3/neutral.c:134 exits */
+          /* kEvEnd: the loop at omp3/neutral.c:134 exits */
+          store_record(h, a, t.rec_out[pid], kRecIdle);
           has = false;
         }
       }
-      /* suspended histories: store the record, queue the id (one atomic per wave) */
-      const unsigned long long m_susp = __ballot(suspend);
-      if (m_susp) {
-        unsigned qbase = 0;
-        const int leader = __ffsll((long long)m_susp) - 1;
-        if ((int)(threadIdx.x & 63) == leader) {
-          qbase = atomicAdd(&t.ctrl[kCtrlCollideCount], (unsigned)__popcll(m_susp));
-        }
-        qbase = __shfl(qbase, leader, 64);
-        if (suspend) {
-          store_record(h, a, t.rec_out[pid]);
-          t.collide_queue[qbase + lane_rank(m_susp)] = (unsigned)pid;
-          has = false;
-        }
+      /* histories handed on: the record carries the state; migrants are counted */
+      if (park != kRecIdle) {
+        store_record(h, a, t.rec_out[pid], park);
+        has = false;
       }
+      nmigrants += (park == kRecMigrate) ? 1u : 0u;
+    }
+  }
+  /* one atomic per wave for the whole kernel: a per-event add to this single
+   * word costs more than the streaming itself (one address takes ~100 adds/us) */
+  {
+    const unsigned wm = wave_sum_u32(nmigrants);
+    if ((threadIdx.x & 63) == 0 && wm) {
+      atomicAdd(&t.ctrl[kCtrlMigrants], wm);
     }
   }
   if (cur_tile >= 0) {
-    flush_window(a, window, tally.ox, tally.oy);
+    flush_window(a, window, win_ox, win_oy);
   }
   flush_counters(a, nprocessed, nfacets, 0u, ncensus);
 }
@@ -395,67 +465,96 @@ hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, 
   return hipGetLastError();
 }
 
-hipError_t launch_solve_tiled(const SolveArgs& a, const TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream) {
+hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
+                              hipEvent_t after_sort, hipEvent_t after_stream, int* npasses) {
+  if (npasses) {
+    *npasses = 0;
+  }
   if (a.nparticles <= 0) {
     return hipSuccess;
   }
-  /* 1. keys -> stable radix sort of (key, particle id) -> tile bounds -> chunks.
-   * Only the low bits that can differ are sorted. */
   const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
-  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
   unsigned bits = 1;
   while ((1u << bits) <= (unsigned)t.ntiles) {
     bits++;
   }
-  size_t temp_bytes = t.sort_temp_bytes;
-  hipError_t err = rocprim::radix_sort_pairs(
-      t.sort_temp, temp_bytes, t.keys_in, t.keys_out, rocprim::counting_iterator<unsigned>(0u),
-      t.order, (size_t)a.nparticles, 0u, bits, stream);
-  if (err != hipSuccess) {
-    return err;
-  }
-  hipLaunchKernelGGL(tile_bounds_kernel, dim3((a.nparticles + 1 + kSortBlock - 1) / kSortBlock),
-                     dim3(kSortBlock), 0, stream, a, t);
-  hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
-  /* (grid sized for the worst case: every particle dead) */
-  hipLaunchKernelGGL(copy_dead_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
-  if (after_sort) {
-    (void)hipEventRecord(after_sort, stream);
-  }
-
-  /* one 1024-thread workgroup per CU (the window takes most of the LDS) */
   int dev = 0;
   int cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
   const size_t lds = tiled_lds_bytes(a);
-  if (a.same_tables) {
-    (void)hipFuncSetAttribute((const void*)stream_kernel<true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stream_kernel<true>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
-  } else {
-    (void)hipFuncSetAttribute((const void*)stream_kernel<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(stream_kernel<false>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
-  }
-  err = hipGetLastError();
-  if (err != hipSuccess) {
-    return err;
-  }
+  (void)hipFuncSetAttribute((const void*)stream_kernel<true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)stream_kernel<false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 
+  for (int pass = 0; pass < kMaxStreamPasses; ++pass) {
+    t.pass = pass;
+    t.allow_migrate = (pass + 1 < kMaxStreamPasses) ? 1 : 0;
+    /* 1. keys -> stable radix sort of (key, record index) -> tile bounds -> chunks.
+     * Only the low bits that can differ are sorted. */
+    hipLaunchKernelGGL(tile_key_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
+    size_t temp_bytes = t.sort_temp_bytes;
+    hipError_t err = rocprim::radix_sort_pairs(
+        t.sort_temp, temp_bytes, t.keys_in, t.keys_out, rocprim::counting_iterator<unsigned>(0u),
+        t.order, (size_t)a.nparticles, 0u, bits, stream);
+    if (err != hipSuccess) {
+      return err;
+    }
+    hipLaunchKernelGGL(tile_bounds_kernel, dim3((a.nparticles + 1 + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, a, t);
+    hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
+    /* (grid sized for the worst case: no record takes part) */
+    hipLaunchKernelGGL(copy_inactive_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
+    if (pass == 0 && after_sort) {
+      (void)hipEventRecord(after_sort, stream);
+    }
+
+    /* 2. one 1024-thread workgroup per CU (the window takes most of the LDS) */
+    if (a.same_tables) {
+      hipLaunchKernelGGL(stream_kernel<true>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+    } else {
+      hipLaunchKernelGGL(stream_kernel<false>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+    }
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+      return err;
+    }
+    ParticleRec* swap = t.rec_in; /* this pass's output is the next stage's input */
+    t.rec_in = t.rec_out;
+    t.rec_out = swap;
+
+    unsigned migrants = 0;
+    err = hipMemcpyAsync(&migrants, &t.ctrl[kCtrlMigrants], sizeof(unsigned),
+                         hipMemcpyDeviceToHost, stream);
+    if (err != hipSuccess) {
+      return err;
+    }
+    err = hipStreamSynchronize(stream);
+    if (err != hipSuccess) {
+      return err;
+    }
+    if (npasses) {
+      *npasses = pass + 1;
+    }
+    if (migrants == 0) {
+      break;
+    }
+  }
   if (after_stream) {
     (void)hipEventRecord(after_stream, stream);
   }
 
   /* 3. the suspended histories: K2 over the collision queue; it counts its
    * events in the second StepCounters record */
+  hipLaunchKernelGGL(collect_suspended_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t,
+                     t.rec_in);
   SolveArgs c = a;
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
-  c.rec = t.rec_out;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
+  c.rec = t.rec_in;
   return launch_solve(c, kVariantEventSorted, stream);
 }
 

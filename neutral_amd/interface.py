@@ -62,7 +62,8 @@ class StepStats(C.Structure):
                 ("same_tables", C.c_int), ("variant", C.c_int),
                 ("sort_ms", C.c_double), ("stream_ms", C.c_double),
                 ("collide_ms", C.c_double), ("stream_facets", C.c_uint64),
-                ("stream_census", C.c_uint64), ("suspended", C.c_uint64)]
+                ("stream_census", C.c_uint64), ("suspended", C.c_uint64),
+                ("stream_passes", C.c_int)]
 
 
 # every symbol include/neutral_hip.h declares

@@ -37,7 +37,7 @@ def main():
             r = sim.step(tt)
             tot_ms += r.kernel_ms
             tot_steps += r.particle_steps
-            per.append(f"{r.kernel_ms:.1f}")
+            per.append(f"{r.kernel_ms:.1f}" + (f"/p{r.stats.stream_passes}" if r.stats.stream_passes > 1 else ""))
         tag = os.path.basename(os.environ.get("NEUTRAL_HIP_LIB", "default"))
         print(f"{tag:40s} {deck} nx={nx} n={n}: {tot_ms:9.1f} ms  {tot_steps / tot_ms / 1e6:8.3f} Gsteps/s"
               f"  tally={float(sim.tally.sum()):.6e}  per-step ms: {' '.join(per)}", flush=True)
