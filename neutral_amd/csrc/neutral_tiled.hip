@@ -60,6 +60,10 @@ constexpr int kChunkParticles = NEUTRAL_CHUNK_PARTICLES;
 #define NEUTRAL_STREAM_REFILL_MIN 32
 #endif
 constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
+#ifndef NEUTRAL_STREAM_REPEAT
+#define NEUTRAL_STREAM_REPEAT 8
+#endif
+constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
 constexpr int kSortBlock = 256;
 
 enum Ctrl : int {
@@ -361,25 +365,33 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
         }
       } else if (has) {
-        /* STREAM: one facet crossing, or the end of the history */
+        /* STREAM: up to kStreamRepeat facet crossings (the pass choice above costs
+         * ~100 scalar instructions; histories cross ~60 facets in a row), or the
+         * end of the history */
         if (h.ev == kEvFacet) {
-          /* outside the window with a long way to go: continue in the pass that
-           * centres a window on wherever the particle is by then */
-          bool leave = false;
-          if (windowed && t.allow_migrate && !tally.inside(a, h.cellx, h.celly)) {
-            const double ahead = h.speed * h.dt_to_census;
-            const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
-                                                 fabs(h.omega_y) * t.cells_per_y);
-            leave = facets_ahead > kMigrateMinFacets;
-          }
-          if (leave) {
-            park = kRecMigrate;
-          } else {
+#pragma unroll 1
+          for (int rep = 0; rep < kStreamRepeat; ++rep) {
+            /* outside the window with a long way to go: continue in the pass that
+             * centres a window on wherever the particle is by then */
+            bool leave = false;
+            if (windowed && t.allow_migrate && !tally.inside(a, h.cellx, h.celly)) {
+              const double ahead = h.speed * h.dt_to_census;
+              const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
+                                                   fabs(h.omega_y) * t.cells_per_y);
+              leave = facets_ahead > kMigrateMinFacets;
+            }
+            if (leave) {
+              park = kRecMigrate;
+              break;
+            }
             nfacets++;
             cross_facet(h, a, tally);
             decide(h, a);
-            if (h.ev == kEvCollision) {
-              park = kRecCollide;
+            if (h.ev != kEvFacet) {
+              if (h.ev == kEvCollision) {
+                park = kRecCollide;
+              }
+              break;
             }
           }
         } else {
