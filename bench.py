@@ -147,6 +147,8 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
 
 
 def main():
+    # ROCr reads this at start-up: multi-process GPU work on this pool needs dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:

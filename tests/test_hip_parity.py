@@ -312,8 +312,10 @@ def test_reinject_resets_state(iface, make_problem, cs):
 
 # ---- the reference's own known answers through validate() --------------------------
 
+@pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("name", ["stream", "csp", "scatter"])
-def test_reference_known_answers_default_decks(iface, make_problem, cs, name, tmp_path, capfd):
+def test_reference_known_answers_default_decks(iface, make_problem, cs, name, variant, tmp_path,
+                                               capfd):
     """problems/neutral.tests:1-3 at the decks' default sizes (4000^2 mesh), checked
     by the library's validate() exactly as main.c:154 does."""
     from neutral_amd import decks
@@ -322,7 +324,7 @@ def test_reference_known_answers_default_decks(iface, make_problem, cs, name, tm
     assert (prob.nx, prob.nparticles, prob.niters) == (d["nx"], d["nparticles"], d["iterations"])
     tests_file = decks.write_tests_file(str(tmp_path / "neutral.tests"), {name: prob.deck})
     iface.set_tests_file(tests_file)
-    sim = iface.Simulation(prob, *cs)
+    sim = iface.Simulation(prob, *cs, variant=variant)
     sim.inject()
     for tt in range(1, prob.niters + 1):
         sim.step(tt)
@@ -337,12 +339,13 @@ def test_reference_known_answers_default_decks(iface, make_problem, cs, name, tm
 
 # ---- BASELINE sizes: size-independent properties -------------------------------------
 
-def test_stream_400_matches_recorded_omp3_counts(iface, make_problem, cs, pins):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_stream_400_matches_recorded_omp3_counts(iface, make_problem, cs, pins, variant):
     """BASELINE config 2 shape at 1e6 particles: exact facet count of the omp3 run
     recorded in BASELINE.md, tally to 1e-9."""
     r = pins["omp3_runs"][1]
     prob = make_problem("stream", nx=r["nx"], nparticles=r["nparticles"], iterations=1)
-    sim = iface.Simulation(prob, *cs)
+    sim = iface.Simulation(prob, *cs, variant=variant)
     sim.inject()
     s = sim.step(1)
     assert (s.facets, s.collisions) == (r["facets"], r["collisions"])
@@ -350,10 +353,11 @@ def test_stream_400_matches_recorded_omp3_counts(iface, make_problem, cs, pins):
     sim.close()
 
 
-def test_split_800_matches_recorded_omp3_counts(iface, make_problem, cs, pins):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_split_800_matches_recorded_omp3_counts(iface, make_problem, cs, pins, variant):
     r = pins["omp3_runs"][4]
     prob = make_problem("split", nx=r["nx"], nparticles=r["nparticles"], iterations=1)
-    sim = iface.Simulation(prob, *cs)
+    sim = iface.Simulation(prob, *cs, variant=variant)
     sim.inject()
     s = sim.step(1)
     assert (s.facets, s.collisions) == (r["facets"], r["collisions"])
@@ -361,10 +365,11 @@ def test_split_800_matches_recorded_omp3_counts(iface, make_problem, cs, pins):
     sim.close()
 
 
-def test_csp_400_ten_steps_matches_recorded_omp3(iface, make_problem, cs, pins):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_csp_400_ten_steps_matches_recorded_omp3(iface, make_problem, cs, pins, variant):
     r = pins["omp3_runs"][3]
     prob = make_problem("csp", nx=r["nx"], nparticles=r["nparticles"], iterations=10)
-    sim = iface.Simulation(prob, *cs)
+    sim = iface.Simulation(prob, *cs, variant=variant)
     sim.inject()
     for tt in range(1, 11):
         s = sim.step(tt)
@@ -380,7 +385,7 @@ def test_stream_tally_is_intensive_in_particle_count(iface, make_problem, cs):
     totals = []
     for n in (100000, 10000000):
         prob = make_problem("stream", nx=400, nparticles=n, iterations=1)
-        sim = iface.Simulation(prob, *cs)
+        sim = iface.Simulation(prob, *cs, variant=2)
         sim.inject()
         s = sim.step(1)
         assert s.collisions == 0 and s.nprocessed == n
@@ -450,3 +455,36 @@ def test_tiled_variant_lazy_export_and_variant_switches(iface, make_problem, cs)
         ref2.close()
     finally:
         iface.set_lazy_export(False)
+
+
+def test_full_size_csp_step_properties(iface, make_problem, cs):
+    """BASELINE config 4 at its full size on one GPU (csp 400^2, 1e8 particles), two
+    timesteps of the default (tiled) pipeline: size-independent properties --
+    every source particle is processed, nobody collides before reaching the block
+    (the source box and the dense block are 0.1 apart, a particle moves 0.138 per
+    step), the tally is non-negative, touches only cells a particle can have
+    reached, and is intensive in N (equal to the 1e6-particle tally per unit N to
+    Monte-Carlo accuracy)."""
+    totals = {}
+    for n in (1000000, 100000000):
+        prob = make_problem("csp", nx=400, nparticles=n, iterations=2)
+        sim = iface.Simulation(prob, *cs, variant=2)
+        iface.set_lazy_export(True)
+        try:
+            sim.inject()
+            r1 = sim.step(1)
+            r2 = sim.step(2)
+        finally:
+            iface.set_lazy_export(False)
+        assert r1.nprocessed == n and r2.nprocessed == n
+        assert r1.collisions == 0 and r1.census == n
+        assert r1.stats.stream_passes == 1
+        t = sim.tally_host().reshape(400, 400)
+        assert np.all(t >= 0.0)
+        # after 2 steps nothing can be further than 2*0.138+ from the source box [0.1,0.3]^2
+        assert np.all(t[:, 240:] == 0.0) and np.all(t[240:, :] == 0.0)
+        totals[n] = (float(t.sum()), (r1.facets + r2.facets) / n)
+        sim.close()
+    # (collisions in the block during step 2 dominate the tally: ~1 % Monte-Carlo noise at 1e6)
+    assert totals[1000000][0] == pytest.approx(totals[100000000][0], rel=3e-2)
+    assert totals[1000000][1] == pytest.approx(totals[100000000][1], rel=2e-3)
