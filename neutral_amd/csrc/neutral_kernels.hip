@@ -1,22 +1,27 @@
 /*
  * neutral_kernels.hip -- hand-written gfx950 kernels of the over-particle
- * transport path.
+ * transport path (the tile-sorted pipeline built on top of them lives in
+ * neutral_tiled.hip).
  *
- *   K0 inject_kernel       initial particle state        (omp3/neutral.c:560-630)
- *   K1 history_kernel      one lane = one history         (omp3/neutral.c:43-206)
- *   K2 history_regroup_kernel  persistent waves, lanes regrouped by next event
- *   tables_equal_kernel    are the two cs tables the same data?
+ *   K0 inject_kernel           initial particle state      (omp3/neutral.c:560-630)
+ *   K1 history_kernel          one lane = one history       (omp3/neutral.c:43-206)
+ *   K2 history_regroup_kernel  persistent waves, lanes regrouped by next event;
+ *                              also the collision stage of the tiled pipeline
+ *   build_cs_index_kernel      exponent-bucketed index over a key array
+ *   tables_equal_kernel        are the two cs tables the same data?
+ *   probe_*                    unit access to the building blocks (known answers)
  *
- * Execution model: one work-item per particle, 64-wide wavefronts, 256-thread
- * workgroups; the grid has nparticles/256 workgroups (>> 256 CUs for every
- * BASELINE configuration), which the dispatcher balances dynamically across
- * the 8 XCDs -- histories vary in length by orders of magnitude, so a static
- * blockIdx->tile map would only hurt here.  Particle state is read once
- * (coalesced SoA), lives in VGPRs for the whole timestep and is written once.
- * The tally mesh, density, edges and cross-section tables (<= ~11 MB together)
- * are shared by all workgroups and stay L2/Infinity-Cache resident; tallies go
- * to the mesh with native f64 atomics (global_atomic_add_f64).  No MFMA: there
- * is no dense contraction anywhere on this path.
+ * Common ground: one work-item per history, 64-wide wavefronts, the whole
+ * history in VGPRs; event bodies shared through neutral_history.h so every
+ * variant computes the same bits.  K1 launches nparticles/256 workgroups
+ * (>> 256 CUs for every BASELINE configuration) and lets the dispatcher balance
+ * histories that differ in length by orders of magnitude across the 8 XCDs;
+ * K2 launches only as many workgroups as stay resident and feeds them from a
+ * queue.  The tally mesh, density, edges and cross-section tables (<= ~11 MB
+ * together) are shared by all workgroups and stay L2/Infinity-Cache resident;
+ * in these two kernels tallies go to the mesh with native f64 atomics
+ * (global_atomic_add_f64).  No MFMA: there is no dense contraction anywhere on
+ * this path.
  */
 #include "neutral_kernels.h"
 
