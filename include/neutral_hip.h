@@ -163,6 +163,8 @@ typedef struct {
   uint64_t stream_facets;
   uint64_t stream_census;
   uint64_t suspended;
+  uint64_t aborted;     /* histories stopped by the event watchdog (2^27 events in one
+                           timestep; 0 for every sane input) */
   int stream_passes;    /* streaming passes the step took (1 unless particles outran
                            the LDS tally window and migrated to another tile) */
 } NeutralHipStepStats;

@@ -475,6 +475,11 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.stream_facets = tiled ? hc[0].nfacets : 0;
   g.last.stream_census = tiled ? hc[0].ncensus : 0;
   g.last.suspended = queue_len;
+  g.last.aborted = (uint64_t)hc[0].aborted + (uint64_t)hc[1].aborted;
+  if (g.last.aborted) {
+    fprintf(stderr, "libneutral_hip: warning: %llu histories exceeded the event watchdog and "
+                    "were stopped.\n", (unsigned long long)g.last.aborted);
+  }
   g.last.stream_passes = tiled ? g.last_passes : 0;
 
   if (!g.quiet) {

@@ -21,6 +21,13 @@
 
 namespace neutral {
 
+/* No history of the reference's decks comes within three orders of magnitude of
+ * this many events per timestep.  A degenerate input that would make the
+ * reference's loop spin (e.g. a zero-length step that never advances) must not
+ * hang a GPU shared with others: such a history is ended as if its time had run
+ * out, and counted in StepCounters::aborted. */
+constexpr unsigned kMaxEventsPerHistory = 1u << 27;
+
 enum Event : int {
   kEvEnd = 0,       /* dt_to_census <= 0: the while loop at :134 exits */
   kEvFacet = 1,
@@ -43,8 +50,9 @@ struct History {
    *   cell_mfp           1/(macro_s+macro_a)              :135
    *   dep_sigma/dep_heat factors of the heating estimator :481-494 */
   double u_x_inv, u_y_inv, dep_sigma, dep_heat;
-  uint64_t pkey;
+  unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
+  unsigned nevents; /* events of this history so far: watchdog only */
   /* the decision taken at the loop head */
   double cell_mfp, distance;
   int x_facet;
@@ -181,7 +189,7 @@ __device__ __forceinline__ void load_particle(History& h, const SolveArgs& a, in
   h.cellx = a.p.cellx[pid];
   h.celly = a.p.celly[pid];
   h.dead = 0;
-  h.pkey = a.pid_base + (uint64_t)pid; /* omp3/neutral.c:89 */
+  h.id = (unsigned)pid;
 }
 
 __device__ __forceinline__ void store_particle(const History& h, const SolveArgs& a, int pid) {
@@ -210,7 +218,7 @@ __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, cons
   h.cellx = r.cellx;
   h.celly = r.celly;
   h.dead = 0;
-  h.pkey = a.pid_base + (uint64_t)r.id;
+  h.id = r.id;
 }
 
 /* ParticleRec::dead doubles as the record's state inside a timestep */
@@ -234,7 +242,7 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.mfp_to_collision = h.mfp_to_collision;
   o.cellx = h.cellx;
   o.celly = h.celly;
-  o.id = (unsigned)(h.pkey - a.pid_base);
+  o.id = h.id;
   o.dead = state;
   r = o;
 }
@@ -250,9 +258,10 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
   h.counter = 0;
+  h.nevents = 0;
   h.dt_to_census = a.dt;
   double rn0, rn1;
-  generate_random_numbers(h.pkey, a.master_key, h.counter++, rn0, rn1);
+  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   h.mfp_to_collision = -log(rn0) / h.macro_s;
   refresh_direction(h);
   refresh_deposition_terms(h);
@@ -275,6 +284,7 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
   h.counter = 1;
+  h.nevents = 0;
   refresh_direction(h);
   refresh_deposition_terms(h);
 }
@@ -282,6 +292,11 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
   if (!(h.dt_to_census > 0.0)) {
+    h.ev = kEvEnd;
+    return;
+  }
+  if (++h.nevents > kMaxEventsPerHistory) {
+    atomicAdd(&a.counters->aborted, 1u);
     h.ev = kEvEnd;
     return;
   }
@@ -316,7 +331,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
 
   const double p_absorb = h.macro_a / (h.macro_s + h.macro_a);
   double rc0, rc1;
-  generate_random_numbers(h.pkey, a.master_key, h.counter++, rc0, rc1);
+  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
 
   if (rc0 < p_absorb) {
     /* absorption: the weight drops; below 1 eV the history ends here */
@@ -346,7 +361,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   macroscopic_from_density(h);
 
   double rn0, rn1;
-  generate_random_numbers(h.pkey, a.master_key, h.counter++, rn0, rn1);
+  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   h.mfp_to_collision = -log(rn0) / h.macro_s;
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);

@@ -66,7 +66,7 @@ struct StepCounters {
   unsigned long long ncollisions;
   unsigned long long ncensus; /* histories that ended in a census event */
   unsigned int queue_head;    /* K2: next unclaimed particle index */
-  unsigned int pad_;
+  unsigned int aborted;       /* histories stopped by the event watchdog (should be 0) */
 };
 
 struct SolveArgs {

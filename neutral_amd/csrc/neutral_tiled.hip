@@ -284,10 +284,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   int win_oy = 0;
   WindowTally<kWindow> tally{(lds_double*)window, 0, 0};
 
-  unsigned nfacets = 0;
-  unsigned nprocessed = 0;
-  unsigned ncensus = 0;
-  unsigned nmigrants = 0;
+  unsigned nfacets = 0;     /* per lane */
+  unsigned w_processed = 0; /* per wave (uniform) */
+  unsigned w_census = 0;
+  unsigned w_migrants = 0;
 
   History h;
   h.ev = kEvEnd;
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         break;
       }
       int park = kRecIdle; /* kRecCollide / kRecMigrate: this lane hands its history on */
+      bool did_census = false;
       if (n_empty >= kStreamRefillMin || n_stream == 0) {
         /* REFILL: take n_empty ids of the chunk */
         int base = 0;
@@ -348,11 +349,15 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           drained = true;
         } else {
           const int mine = base + lane_rank(m_empty);
+          /* wave-level bookkeeping (scalar registers, not one VGPR per counter) */
+          if (t.pass == 0) {
+            const int left = chunk_end - base;
+            w_processed += (unsigned)((n_empty < left) ? n_empty : left);
+          }
           if (!has && mine < chunk_end) {
             pid = mine; /* this history's slot in rec_out */
             load_record(h, a, t.rec_in[t.order[mine]]);
             if (t.pass == 0) {
-              nprocessed++;
               prologue<kSameTables>(h, a, ix);
             } else {
               resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
@@ -396,12 +401,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
         } else {
           if (h.ev == kEvCensus) {
-            ncensus++;
             census(h, a, tally);
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           store_record(h, a, t.rec_out[pid], kRecIdle);
           has = false;
+          did_census = (h.ev == kEvCensus);
         }
       }
       /* histories handed on: the record carries the state; migrants are counted */
@@ -409,21 +414,26 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         store_record(h, a, t.rec_out[pid], park);
         has = false;
       }
-      nmigrants += (park == kRecMigrate) ? 1u : 0u;
+      w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
+      w_census += (unsigned)__popcll(__ballot(did_census));
     }
   }
   /* one atomic per wave for the whole kernel: a per-event add to this single
    * word costs more than the streaming itself (one address takes ~100 adds/us) */
-  {
-    const unsigned wm = wave_sum_u32(nmigrants);
-    if ((threadIdx.x & 63) == 0 && wm) {
-      atomicAdd(&t.ctrl[kCtrlMigrants], wm);
-    }
+  if ((threadIdx.x & 63) == 0 && w_migrants) {
+    atomicAdd(&t.ctrl[kCtrlMigrants], w_migrants);
   }
   if (cur_tile >= 0) {
     flush_window(a, window, win_ox, win_oy);
   }
-  flush_counters(a, nprocessed, nfacets, 0u, ncensus);
+  {
+    const unsigned wf = wave_sum_u32(nfacets);
+    if ((threadIdx.x & 63) == 0) {
+      if (w_processed) atomicAdd(&a.counters->nprocessed, (unsigned long long)w_processed);
+      if (wf) atomicAdd(&a.counters->nfacets, (unsigned long long)wf);
+      if (w_census) atomicAdd(&a.counters->ncensus, (unsigned long long)w_census);
+    }
+  }
 }
 
 /* ---- launcher ---------------------------------------------------------------------- */

@@ -63,7 +63,7 @@ class StepStats(C.Structure):
                 ("sort_ms", C.c_double), ("stream_ms", C.c_double),
                 ("collide_ms", C.c_double), ("stream_facets", C.c_uint64),
                 ("stream_census", C.c_uint64), ("suspended", C.c_uint64),
-                ("stream_passes", C.c_int)]
+                ("aborted", C.c_uint64), ("stream_passes", C.c_int)]
 
 
 # every symbol include/neutral_hip.h declares
