@@ -56,6 +56,22 @@ def algorithmic_bytes(histories, facets, collisions, census, same_tables):
             facets * 24 + census * 16)
 
 
+def touched_bytes(kernel, histories, facets, collisions, census):
+    """Global-memory bytes THIS implementation's algorithm touches (not HBM
+    traffic: most of it is served by L1/L2): an 80-B record in and out plus the
+    4-B sort index per history handled, 8 B density, a bucketed cs lookup (two
+    2-B index entries, ~2 key probes, 32 B of bracket keys/values = 52 B) per
+    history and per collision, 32 B of edges per event, 8 B density per facet.
+    Tallies of the streaming kernel go to LDS; the collision kernel's few
+    tallies are 16-B RMWs."""
+    lookup = 52
+    b = histories * (160 + 4 + 8 + lookup) + (facets + collisions + census) * 32 + \
+        collisions * lookup + facets * 8
+    if kernel != "stream_kernel":
+        b += (facets + census) * 16
+    return b
+
+
 def kernel_rooflines(results, same_tables):
     """Per-kernel (name, mean ms per launch, mean algorithmic bytes per launch)
     over the timed launches of this rank.  The tiled variant has two history
@@ -66,17 +82,21 @@ def kernel_rooflines(results, same_tables):
         b = sum(algorithmic_bytes(r.nprocessed, r.facets, r.collisions, r.census, same_tables)
                 for r in results) / n
         name = "history_kernel" if results[0].stats.variant == 0 else "history_regroup_kernel"
-        return [(name, sum(r.kernel_ms for r in results) / n, b)]
-    bs = bc = 0.0
+        return [(name, sum(r.kernel_ms for r in results) / n, b, None)]
+    bs = bc = ts = tc = 0.0
     for r in results:
         st = r.stats
         bs += algorithmic_bytes(r.nprocessed, st.stream_facets, 0, st.stream_census, same_tables)
         bc += algorithmic_bytes(st.suspended, r.facets - st.stream_facets, r.collisions,
                                 r.census - st.stream_census, same_tables)
-    return [("stream_kernel", sum(r.stats.stream_ms for r in results) / n, bs / n),
-            ("history_regroup_kernel", sum(r.stats.collide_ms for r in results) / n, bc / n),
+        ts += touched_bytes("stream_kernel", r.nprocessed, st.stream_facets, 0, st.stream_census)
+        tc += touched_bytes("history_regroup_kernel", st.suspended, r.facets - st.stream_facets,
+                            r.collisions, r.census - st.stream_census)
+    return [("stream_kernel", sum(r.stats.stream_ms for r in results) / n, bs / n, ts / n),
+            ("history_regroup_kernel", sum(r.stats.collide_ms for r in results) / n, bc / n,
+             tc / n),
             ("tile sort (rocPRIM radix sort + 3 small kernels)",
-             sum(r.stats.sort_ms for r in results) / n, 0.0)]
+             sum(r.stats.sort_ms for r in results) / n, 0.0, 0.0)]
 
 
 def measured_traffic(deck, nx, ntotal, variant, kernel):
@@ -273,9 +293,17 @@ def main():
                              "traffic": measured_traffic(deck, nx, ntotal, int(stats.variant),
                                                          dom[0]),
                              "kernel": dom[0], "kernel_ms_avg": dom[1],
-                             "algorithmic_bytes_per_launch": dom[2]},
+                             "algorithmic_bytes_per_launch": dom[2],
+                             "note": "algorithmic bytes price each cs lookup at the reference's "
+                                     "15 probes (SURVEY 8d); this implementation's bucketed "
+                                     "index touches far fewer, see own_algorithm",
+                             "own_algorithm": None if dom[3] is None else {
+                                 "touched_bytes_per_launch": dom[3],
+                                 "achieved": dom[3] / (dom[1] * 1e-3) / 1e9,
+                                 "frac": dom[3] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
                 "kernels": [{"name": k[0], "ms_per_launch": k[1],
-                             "algorithmic_bytes_per_launch": k[2]} for k in kernels],
+                             "algorithmic_bytes_per_launch": k[2],
+                             "touched_bytes_per_launch": k[3]} for k in kernels],
             }
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(deck, nx, K, args.cpu_seconds, tmp)
