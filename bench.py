@@ -129,6 +129,10 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=2,
                     help="0 over-particle, 1 event-regrouped, 2 tiled (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="testing only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work of the cpu_baseline sample")
     return ap.parse_args()
@@ -174,6 +178,7 @@ def main():
     if args.gpus > 1 and world == 1:
         # not under a launcher: start one (child process; nothing here has touched the GPU)
         port = os.environ.get("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
@@ -189,10 +194,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_device:
+        if args.backend != "gloo":
+            raise SystemExit("--share-device needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from neutral_amd import cs_table, decks, host
     from neutral_amd import interface as iface

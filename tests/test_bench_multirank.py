@@ -1,0 +1,44 @@
+"""bench.py's N > 1 path on real hardware: two ranks (gloo, sharing the one GPU
+of the test box) each run the HIP path on their particle shard and all-reduce
+the step tally; totals must equal the one-rank run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, gpu_available
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
+
+
+def _bench(extra, nproc):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable]
+    if nproc > 1:
+        base += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                 "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200)]
+    cmd = base + [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3",
+                  "--warmup", "1", "--nparticles", "3000001", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_equals_one_rank():
+    one = _bench([], 1)
+    two = _bench(["--backend", "gloo", "--share-device"], 2)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["events"] == one["events"]                      # exact event totals
+    assert two["global_tally"] == pytest.approx(one["global_tally"], rel=1e-12)
+    for d in (one, two):
+        assert d["metric"] == "particle-steps/sec" and d["unit"] == "particle-steps/s"
+        assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+        assert d["value"] == pytest.approx(
+            (d["events"]["facets"] + d["events"]["collisions"] + d["events"]["census"])
+            / (d["ms_per_step"] * 1e-3 * d["steps"]), rel=1e-6)
