@@ -155,12 +155,13 @@ hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, 
                                  hipStream_t stream);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
 /* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
- * collision kernel.  The optional events are recorded after the first sort and
- * after the last streaming pass.  Synchronises the stream once per pass (the
+ * collision kernel.  The optional events are recorded after the first sort,
+ * after the last streaming pass and after the collision queue is built.  Synchronises the stream once per pass (the
  * migrant count decides whether another pass runs).  On return t.rec_in holds
  * the records of this step (t.rec_in / t.rec_out are swapped per pass). */
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream, int* npasses);
+                              hipEvent_t after_sort, hipEvent_t after_stream,
+                              hipEvent_t after_collect, int* npasses);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

@@ -488,7 +488,8 @@ hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, 
 }
 
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream, int* npasses) {
+                              hipEvent_t after_sort, hipEvent_t after_stream,
+                              hipEvent_t after_collect, int* npasses) {
   if (npasses) {
     *npasses = 0;
   }
@@ -572,6 +573,9 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
    * events in the second StepCounters record */
   hipLaunchKernelGGL(collect_suspended_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t,
                      t.rec_in);
+  if (after_collect) {
+    (void)hipEventRecord(after_collect, stream);
+  }
   SolveArgs c = a;
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
