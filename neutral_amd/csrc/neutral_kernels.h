@@ -123,6 +123,7 @@ struct TiledArgs {
   uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants */
+  int chunk_particles;     /* particles one workgroup takes at a time */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */
   int allow_migrate;       /* 0 on the last permitted pass: finish with global atomics */
   double cells_per_x;      /* nx / mesh width, ny / mesh height: for the estimate of how */

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
  * Exit: the queue head only grows, a wave leaves when the queue is drained and
  * none of its lanes holds a particle -- every wave reaches that state.
  */
-constexpr int kQueueChunk = 128;
+constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is plentiful */
 #ifndef NEUTRAL_REFILL_MIN
 #define NEUTRAL_REFILL_MIN 8
 #endif
@@ -216,6 +216,14 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
   const GlobalTally tally;
   /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
   const int nwork = a.queue ? (int)*a.queue_len : a.nparticles;
+  /* A history is a serial chain (931 collisions of ~7 us for a csp collider), so
+   * the kernel can never finish faster than the longest chain of histories one
+   * wave works through.  When there are fewer ids than lanes * 2, claim them in
+   * smaller chunks so that every wave gets an equal share instead of a few
+   * waves getting two generations each while the other SIMDs idle. */
+  const int nwaves = (int)gridDim.x * (kBlock / 64);
+  int chunk = (nwork + nwaves - 1) / nwaves;
+  chunk = (chunk < 8) ? 8 : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
 
   History h;
   int pid = -1;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       if (cur >= end) {
         int base = 0;
         if ((threadIdx.x & 63) == 0) {
-          base = (int)atomicAdd(&a.counters->queue_head, (unsigned)kQueueChunk);
+          base = (int)atomicAdd(&a.counters->queue_head, (unsigned)chunk);
         }
         base = __builtin_amdgcn_readfirstlane(base);
         /* the head can overshoot nparticles by at most (#waves * chunk) */
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
           cur = end = 0;
         } else {
           cur = base;
-          end = (base + kQueueChunk < nwork) ? base + kQueueChunk : nwork;
+          end = (base + chunk < nwork) ? base + chunk : nwork;
         }
       }
       if (!drained) {

@@ -52,10 +52,12 @@ constexpr int kTile = 16;                          /* cells per tile edge */
 constexpr int kWindow = 128;                       /* cells per LDS window edge */
 constexpr int kMargin = (kWindow - kTile) / 2;     /* window reach beyond the tile */
 constexpr int kStreamBlock = 1024;                 /* 16 waves share one window */
-#ifndef NEUTRAL_CHUNK_PARTICLES
-#define NEUTRAL_CHUNK_PARTICLES 32768
-#endif
-constexpr int kChunkParticles = NEUTRAL_CHUNK_PARTICLES;
+/* A chunk is what one workgroup takes at a time from one tile's particles: big
+ * enough to amortise its two barriers and a window move, small enough that
+ * every workgroup gets several (the host picks the size from the particle
+ * count: tiled_chunk_particles). */
+constexpr int kChunkParticlesMax = 32768;
+constexpr int kChunkParticlesMin = 4096;
 #ifndef NEUTRAL_STREAM_REFILL_MIN
 #define NEUTRAL_STREAM_REFILL_MIN 32
 #endif
@@ -80,7 +82,7 @@ constexpr double kMigrateMinFacets = 8.0;
 /* a chunk smaller than this tallies straight to HBM: flushing a 16 384-cell
  * window costs more than the few atomics it would save, and its particles never
  * migrate (sparse problems degrade to the plain event-regrouped behaviour) */
-constexpr int kWindowMinParticles = 4096;
+constexpr int kWindowMinParticles = 2048;
 
 __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly) {
   return (celly / kTile) * t.tiles_x + (cellx / kTile);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   unsigned nch = 0;
   for (int i = lo; i < hi; ++i) {
     const unsigned c = t.tile_offset[i + 1] - t.tile_offset[i];
-    nch += (c + kChunkParticles - 1) / kChunkParticles;
+    nch += (c + t.chunk_particles - 1) / t.chunk_particles;
   }
   s_chunks[tid] = nch;
   __syncthreads();
@@ -211,8 +213,8 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   for (int i = lo; i < hi; ++i) {
     const unsigned begin = t.tile_offset[i];
     const unsigned end = t.tile_offset[i + 1];
-    for (unsigned b = begin; b < end; b += kChunkParticles) {
-      const unsigned e = (b + kChunkParticles < end) ? b + kChunkParticles : end;
+    for (unsigned b = begin; b < end; b += (unsigned)t.chunk_particles) {
+      const unsigned e = (b + t.chunk_particles < end) ? b + t.chunk_particles : end;
       if (chunk < (unsigned)t.max_chunks) {
         t.chunks[chunk] = make_uint4(b, e, (unsigned)i, 0u);
       }
@@ -462,11 +464,19 @@ size_t tiled_sort_temp_bytes(int nparticles, int ntiles) {
   return bytes;
 }
 
+int tiled_chunk_particles(int nparticles, int compute_units) {
+  /* about six chunks per workgroup when every particle is live */
+  long long c = (long long)nparticles / ((long long)compute_units * 6);
+  if (c > kChunkParticlesMax) c = kChunkParticlesMax;
+  if (c < kChunkParticlesMin) c = kChunkParticlesMin;
+  return (int)c;
+}
+
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks) {
   *tiles_x = (nx + kTile - 1) / kTile;
   *tiles_y = (ny + kTile - 1) / kTile;
   /* every tile can end with one partial chunk */
-  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticles + 1;
+  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesMin + 1;
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, int n,
@@ -506,6 +516,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
+  t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
   const size_t lds = tiled_lds_bytes(a);
   (void)hipFuncSetAttribute((const void*)stream_kernel<true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

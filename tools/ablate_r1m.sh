@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+run() { python tools/ablate.py "$@" 2>&1 | grep -v amdgpu.ids | tail -1; }
+run csp 400 100000000 10 2
+run csp 400 12500000 10 2
+run csp 400 12500000 10 1
+run stream 400 10000000 1 2
+run split 800 12500000 1 2
