@@ -34,12 +34,14 @@ namespace neutral {
 constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
- * (second __launch_bounds__ argument): 4 <=> at most 128 VGPRs */
+ * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs.  K2 needs 141
+ * without spilling; at 4 waves (128 VGPRs) it spills 32 B/lane and is no faster:
+ * the kernel is bound by VALU issue, not by latency (profiles/r01d). */
 #ifndef NEUTRAL_K1_WAVES
 #define NEUTRAL_K1_WAVES 3
 #endif
 #ifndef NEUTRAL_K2_WAVES
-#define NEUTRAL_K2_WAVES 4
+#define NEUTRAL_K2_WAVES 3
 #endif
 
 /* ---- K0: injection --------------------------------------------------------- */
