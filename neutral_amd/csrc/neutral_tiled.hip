@@ -63,7 +63,7 @@ constexpr int kChunkParticlesMin = 4096;
 #endif
 constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
 #ifndef NEUTRAL_STREAM_REPEAT
-#define NEUTRAL_STREAM_REPEAT 8
+#define NEUTRAL_STREAM_REPEAT 16
 #endif
 constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
 constexpr int kSortBlock = 256;
