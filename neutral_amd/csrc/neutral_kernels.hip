@@ -167,6 +167,9 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
  * none of its lanes holds a particle -- every wave reaches that state.
  */
 constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is plentiful */
+#ifndef NEUTRAL_QUEUE_CHUNK_MIN
+#define NEUTRAL_QUEUE_CHUNK_MIN 8
+#endif
 #ifndef NEUTRAL_REFILL_MIN
 #define NEUTRAL_REFILL_MIN 8
 #endif
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
    * waves getting two generations each while the other SIMDs idle. */
   const int nwaves = (int)gridDim.x * (kBlock / 64);
   int chunk = (nwork + nwaves - 1) / nwaves;
-  chunk = (chunk < 8) ? 8 : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
+  chunk = (chunk < NEUTRAL_QUEUE_CHUNK_MIN) ? NEUTRAL_QUEUE_CHUNK_MIN : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
 
   History h;
   int pid = -1;
