@@ -287,10 +287,9 @@ def main():
                 "vs_baseline": None,
                 "dtype": "f64",
                 "data": "synthetic",
-                "config": {"workload": f"problems/csp-style deck '{deck}' at nx=ny={nx}, "
-                                       f"{ntotal} particles, {K} timesteps"
-                           if deck == "csp" else
-                           f"deck '{deck}' at nx=ny={nx}, {ntotal} particles, {K} timesteps",
+                "config": {"workload": f"problems/{deck}.params at nx=ny={nx}, {ntotal} particles, "
+                                       f"{K} timesteps (BASELINE.json: the metric is quoted on csp "
+                                       "400x400, 1e8 particles)",
                            "deck": deck, "nx": nx, "ny": nx, "nparticles": ntotal,
                            "timesteps": K, "parallelism": f"particle-shard x{world}",
                            "kernel_variant": int(stats.variant)},
