@@ -18,6 +18,8 @@ One JSON line on rank 0 (see README "bench contract"), with
                launch / mean HIP-event duration of the history kernel
   cpu_baseline the CPU oracle timed on this host's cores on a bounded sample of
                the same workload (rank 0, N = 1 only)
+  parity_vs_cpu  the HIP path re-run on that same sample: per-cell tally L2
+               against the oracle's tally ("tally L2 vs omp3"), exact event counts
 """
 import argparse
 import json
@@ -156,18 +158,22 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
         r.inject()
         steps = 0
         t0 = time.perf_counter()
+        r.events = []
         for tt in range(1, its + 1):
-            steps += r.step(tt).particle_steps
-        return steps, time.perf_counter() - t0
+            res = r.step(tt)
+            steps += res.particle_steps
+            r.events.append((res.nprocessed, res.facets, res.collisions, res.census))
+        return steps, time.perf_counter() - t0, r
 
     n0 = 100_000
-    s0, t0 = run(n0)
+    s0, t0, _ = run(n0)
     n = int(min(max(n0, n0 * target_seconds / max(t0, 1e-3)), 20_000_000))
     n = max(n0, (n // 1000) * 1000)
-    steps, secs = run(n)
-    return {"value": steps / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{deck} {nx}x{nx}, {n} particles, {its} timesteps, "
-                      f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)"}
+    steps, secs, oracle_run = run(n)
+    out = {"value": steps / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{deck} {nx}x{nx}, {n} particles, {its} timesteps, "
+                     f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)"}
+    return out, oracle_run, n
 
 
 def main():
@@ -316,10 +322,31 @@ def main():
                              "touched_bytes_per_launch": k[3]} for k in kernels],
             }
             if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(deck, nx, K, args.cpu_seconds, tmp)
+                out["cpu_baseline"], oracle_run, n_sample = cpu_baseline(deck, nx, K,
+                                                                         args.cpu_seconds, tmp)
                 out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                # "tally L2 vs omp3" (BASELINE.json metric): the HIP path on the CPU
+                # baseline's own sample problem, per-cell tally against the oracle's
+                sim.close()
+                check = iface.Simulation(oracle_run.p, keys, values, device=local_rank,
+                                         variant=args.variant)
+                check.inject()
+                ev = []
+                for tt in range(1, K + 1):
+                    r = check.step(tt)
+                    ev.append((r.nprocessed, r.facets, r.collisions, r.census))
+                t_gpu = check.tally_host()
+                out["parity_vs_cpu"] = {
+                    "sample_particles": n_sample,
+                    "tally_l2_rel": float(np.linalg.norm(t_gpu - oracle_run.tally) /
+                                          np.linalg.norm(oracle_run.tally)),
+                    "tally_sum_rel": float(abs(t_gpu.sum() - oracle_run.tally.sum()) /
+                                           abs(oracle_run.tally.sum())),
+                    "event_counts_equal": ev == oracle_run.events,
+                    "tolerance": 1e-6}
+                check.close()
             print(json.dumps(out), flush=True)
-        sim.close()
+        sim.close()  # (idempotent)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
