@@ -116,22 +116,31 @@ def test_oracle_reproduces_recorded_omp3_runs(pins, make_problem, cs, i):
     assert run.tally_sum() == pytest.approx(r["tally"], rel=1e-13)
 
 
-def _known_answer(make_problem, cs, name):
+def _known_answer(make_problem, cs, name, pins=None):
     d = decks.STANDARD_DECKS[name]
-    run, *_ = _run_oracle(make_problem, cs, name, d["nx"], d["nparticles"], d["iterations"])
+    run, facets, collisions, _ = _run_oracle(make_problem, cs, name, d["nx"], d["nparticles"],
+                                             d["iterations"])
     expected = decks.KNOWN_ANSWERS[name]
     assert abs(run.tally_sum() - expected) / expected < decks.VALIDATE_TOLERANCE
+    if pins is not None:
+        # the omp3 backend's own output at this size, recorded by the survey
+        rec = next(r for r in pins["omp3_default_runs"] if r["deck"] == name)
+        if rec["facets"] is not None:
+            assert facets == rec["facets"]
+        if rec["collisions"] is not None:
+            assert collisions == rec["collisions"]
+        assert run.tally_sum() == pytest.approx(rec["tally"], rel=1e-13)
 
 
-def test_known_answer_stream_default_deck(make_problem, cs):
+def test_known_answer_stream_default_deck(make_problem, cs, pins):
     """problems/neutral.tests:2 at the deck's default size (4000^2, 1e6 particles)."""
-    _known_answer(make_problem, cs, "stream")
+    _known_answer(make_problem, cs, "stream", pins)
 
 
 @pytest.mark.fullkat
 @pytest.mark.skipif(os.environ.get("NEUTRAL_FULL_KATS") != "1",
                     reason="minutes of CPU; set NEUTRAL_FULL_KATS=1 (log: oracle/pins/)")
 @pytest.mark.parametrize("name", ["csp", "scatter"])
-def test_known_answer_default_decks(make_problem, cs, name):
+def test_known_answer_default_decks(make_problem, cs, name, pins):
     """problems/neutral.tests:1,3 at the decks' default sizes."""
-    _known_answer(make_problem, cs, name)
+    _known_answer(make_problem, cs, name, pins)
