@@ -394,10 +394,17 @@ def test_stream_tally_is_intensive_in_particle_count(iface, make_problem, cs):
     assert totals[0] == pytest.approx(totals[1], rel=2e-3)
 
 
-def test_kernel_variants_are_bitwise_identical_in_particle_state(iface, make_problem, cs):
-    """K2 runs the same event bodies with the same RNG counters as K1, so particle
-    end states agree bit for bit; tallies differ only by summation order."""
-    prob = make_problem("csp", nx=100, nparticles=50000, iterations=3, dt=1.0e-6)
+@pytest.mark.parametrize("deck,nx,n,dt", [("csp", 100, 50000, 1.0e-6), ("split", 200, 60000, 5.0e-7),
+                                          ("stream", 400, 30000, None), ("scatter", 64, 20000, None)])
+def test_kernel_variants_are_bitwise_identical_in_particle_state(iface, make_problem, cs, deck, nx,
+                                                                 n, dt):
+    """K2/K3 run the same event bodies with the same RNG counters as K1, so particle
+    end states agree bit for bit; tallies differ only by summation order.  The
+    stream case makes particles outrun the LDS window (multi-pass migration)."""
+    kw = dict(nx=nx, nparticles=n, iterations=3)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
     out = []
     for variant in (0, 1, 2):
         sim = iface.Simulation(prob, *cs, variant=variant)
