@@ -119,6 +119,27 @@ def measured_traffic(deck, nx, ntotal, variant, kernel):
     return None
 
 
+def measured_copy_bandwidth(device):
+    """On-box HBM stream-copy rate (GB/s, read + write bytes) of a 1-GiB f64
+    device-to-device copy: the measured denominator SURVEY.md 8(d) asks for next
+    to the 8 TB/s spec figure."""
+    import torch
+    n = 1 << 27
+    a = torch.empty(n, dtype=torch.float64, device=device)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    b.copy_(a)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        b.copy_(a)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    del a, b
+    return 2.0 * n * 8 * reps / dt / 1e9
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,6 +342,7 @@ def main():
                              "algorithmic_bytes_per_launch": k[2],
                              "touched_bytes_per_launch": k[3]} for k in kernels],
             }
+            out["roofline"]["hbm_copy_measured_gbs"] = measured_copy_bandwidth(sim.device)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], oracle_run, n_sample = cpu_baseline(deck, nx, K,
                                                                          args.cpu_seconds, tmp)
