@@ -34,14 +34,17 @@ namespace neutral {
 constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
- * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs.  K2 needs 141
- * without spilling; at 4 waves (128 VGPRs) it spills 32 B/lane and is no faster:
- * the kernel is bound by VALU issue, not by latency (profiles/r01d). */
+ * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  K2
+ * needs 141 without spilling; the two instantiations make opposite choices,
+ * see history_regroup_kernel (profiles/r01e/baseline_configs.log). */
 #ifndef NEUTRAL_K1_WAVES
 #define NEUTRAL_K1_WAVES 3
 #endif
 #ifndef NEUTRAL_K2_WAVES
-#define NEUTRAL_K2_WAVES 3
+#define NEUTRAL_K2_WAVES 4
+#endif
+#ifndef NEUTRAL_K2_QUEUE_WAVES
+#define NEUTRAL_K2_QUEUE_WAVES 3
 #endif
 
 /* ---- K0: injection --------------------------------------------------------- */
@@ -182,16 +185,22 @@ constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
 /* final state of a history: into the SoA store, or into its record in queue mode */
+template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
-  if (a.queue) {
+  if (kQueue) {
     store_record(h, a, a.rec[pid], h.dead ? kRecDead : kRecIdle);
   } else {
     store_particle(h, a, pid);
   }
 }
 
-template <bool kSameTables>
-__global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kernel(SolveArgs a) {
+/* kQueue = false: variant 1, every particle of the SoA store, streamers and
+ * colliders mixed (parked lanes make occupancy matter: 4 waves/SIMD, small
+ * spill); kQueue = true: the collision stage of the tiled pipeline, histories
+ * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
+template <bool kSameTables, bool kQueue>
+__global__ __launch_bounds__(kBlock, kQueue ? NEUTRAL_K2_QUEUE_WAVES : NEUTRAL_K2_WAVES)
+void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
   unsigned ncollisions = 0;
   unsigned nprocessed = 0;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
 
   const GlobalTally tally;
   /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
-  const int nwork = a.queue ? (int)*a.queue_len : a.nparticles;
+  const int nwork = kQueue ? (int)*a.queue_len : a.nparticles;
   /* A history is a serial chain (931 collisions of ~7 us for a csp collider), so
    * the kernel can never finish faster than the longest chain of histories one
    * wave works through.  When there are fewer ids than lanes * 2, claim them in
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
         bool take = (want == kWantRefill) && (mine < end);
         const int avail = end - cur;
         cur += (n_refill < avail) ? n_refill : avail;
-        if (a.queue) {
+        if (kQueue) {
           /* a history the streaming kernel suspended: its record is the state */
           if (take) {
             pid = (int)a.queue[mine];
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
       if (want == kWantCollide) {
         ncollisions++;
         if (collide<kSameTables>(h, a, ix, tally)) {
-          put_back(h, a, pid);
+          put_back<kQueue>(h, a, pid);
           want = kWantRefill;
         } else {
           decide(h, a);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K2_WAVES) void history_regroup_kern
             ncensus++;
             census(h, a, tally);
           }
-          put_back(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
+          put_back<kQueue>(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
         }
       }
@@ -506,19 +515,27 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
      * the worst case, surplus waves drain at their first refill */
     const int chunks = (a.nparticles + kQueueChunk - 1) / kQueueChunk;
     const int want_blocks = (chunks + (kBlock / 64) - 1) / (kBlock / 64);
-    int grid = a.same_tables ? resident_blocks(history_regroup_kernel<true>)
-                             : resident_blocks(history_regroup_kernel<false>);
-    if (grid > want_blocks) {
-      grid = want_blocks;
-    }
     size_t lds = a.scatter_index ? sizeof(unsigned short) * (a.scatter_index_n + 1) : 0;
     if (!a.same_tables && a.absorb_index) {
       lds += sizeof(unsigned short) * (a.absorb_index_n + 1);
     }
-    if (a.same_tables) {
-      hipLaunchKernelGGL(history_regroup_kernel<true>, dim3(grid), dim3(kBlock), lds, stream, a);
+    auto launch = [&](auto kernel) {
+      int grid = resident_blocks(kernel);
+      if (grid > want_blocks) {
+        grid = want_blocks;
+      }
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+    };
+    if (a.queue) {
+      if (a.same_tables) {
+        launch(history_regroup_kernel<true, true>);
+      } else {
+        launch(history_regroup_kernel<false, true>);
+      }
+    } else if (a.same_tables) {
+      launch(history_regroup_kernel<true, false>);
     } else {
-      hipLaunchKernelGGL(history_regroup_kernel<false>, dim3(grid), dim3(kBlock), lds, stream, a);
+      launch(history_regroup_kernel<false, false>);
     }
     return hipGetLastError();
   }
