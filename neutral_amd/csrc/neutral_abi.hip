@@ -168,8 +168,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   neutral::tiled_geometry(nx, ny, nparticles, &tx, &ty, &max_chunks);
   neutral::TiledArgs& t = g.tiled;
   if (nparticles > g.tiled_particles || tx * ty > g.tiled_tiles) {
-    void* old[] = {t.order,    t.collide_queue, t.keys_in, t.keys_out,
-                   t.sort_temp, t.tile_offset,   t.rec_in,  t.rec_out};
+    void* old[] = {t.order,     t.collide_queue, t.keys_in, t.keys_out, t.sort_temp,
+                   t.tile_offset, t.rec_in,      t.rec_out, t.info_in,  t.info_out};
     g.rec_valid = false;
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
@@ -181,6 +181,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     HIP_CHECK(hipMalloc((void**)&t.keys_out, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
     HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
+    HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
     t.sort_temp_bytes = neutral::tiled_sort_temp_bytes(nparticles, tx * ty);
     HIP_CHECK(hipMalloc(&t.sort_temp, t.sort_temp_bytes ? t.sort_temp_bytes : 16));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty + 2)));
@@ -368,6 +370,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.queue = nullptr;
   a.queue_len = nullptr;
   a.rec = nullptr;
+  a.slot_info = nullptr;
+  a.tiles_x = 0;
 
   HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
   const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
@@ -392,7 +396,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     if (!g.rec_valid || g.rec_owner != (const void*)particles->x ||
         g.rec_count != a.nparticles) {
       sync_soa(); /* a previous owner's pending write-back */
-      HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, a.nparticles, g.stream));
+      HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
+                                               g.tiled.tiles_x, x_off, y_off, a.nparticles,
+                                               g.stream));
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
       g.rec_count = a.nparticles;

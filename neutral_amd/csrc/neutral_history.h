@@ -229,6 +229,14 @@ enum RecState : int {
   kRecMigrate = 3,   /* left its tally window, waits for the next streaming pass */
 };
 
+constexpr int kTileCells = 16; /* cells per tile edge of the tiled variant */
+
+/* record summary: state in the top two bits, tile of the cell below */
+__device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x) {
+  return ((unsigned)state << 30) |
+         (unsigned)((celly / kTileCells) * tiles_x + (cellx / kTileCells));
+}
+
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
                                              ParticleRec& r, int state) {
   ParticleRec o;

@@ -108,12 +108,19 @@ struct SolveArgs {
   const unsigned* queue;
   const unsigned* queue_len; /* [device] number of valid entries */
   ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
+  unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
+  int tiles_x;               /* tiles per mesh row, for the summary's tile field */
 };
 
 /* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
 struct TiledArgs {
   ParticleRec* rec_in;     /* nparticles: records in last step's order */
   ParticleRec* rec_out;    /* nparticles: records in this step's tile order */
+  /* 4-B summary of each record, written with it: state << 30 | tile of its cell.
+   * The sort keys and the collision queue are built from these 4 bytes instead
+   * of a strided read of the 80-B records. */
+  unsigned* info_in;
+  unsigned* info_out;
   unsigned* order;         /* nparticles: rec_in indices sorted by tile (dead ones last) */
   unsigned* keys_in;       /* nparticles: tile of each particle, ntiles when dead */
   unsigned* keys_out;      /* nparticles: sorted keys */
@@ -151,7 +158,8 @@ hipError_t launch_tables_equal(const double* ka, const double* va, const double*
 size_t tiled_lds_bytes(const SolveArgs& a);
 size_t tiled_sort_temp_bytes(int nparticles, int ntiles);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
-hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, int n, hipStream_t stream);
+hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
+                                 int tiles_x, int x_off, int y_off, int n, hipStream_t stream);
 hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, int n,
                                  hipStream_t stream);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);

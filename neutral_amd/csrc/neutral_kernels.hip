@@ -188,7 +188,9 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
 template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
-    store_record(h, a, a.rec[pid], h.dead ? kRecDead : kRecIdle);
+    const int state = h.dead ? kRecDead : kRecIdle;
+    store_record(h, a, a.rec[pid], state);
+    a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x);
   } else {
     store_particle(h, a, pid);
   }

@@ -48,7 +48,7 @@
 
 namespace neutral {
 
-constexpr int kTile = 16;                          /* cells per tile edge */
+constexpr int kTile = kTileCells;                  /* cells per tile edge (16) */
 constexpr int kWindow = 128;                       /* cells per LDS window edge */
 constexpr int kMargin = (kWindow - kTile) / 2;     /* window reach beyond the tile */
 constexpr int kStreamBlock = 1024;                 /* 16 waves share one window */
@@ -95,10 +95,10 @@ __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly)
 __global__ __launch_bounds__(kSortBlock) void tile_key_kernel(SolveArgs a, TiledArgs t) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   if (i < a.nparticles) {
-    const ParticleRec& r = t.rec_in[i];
-    const bool active = (t.pass == 0) ? (r.dead != kRecDead) : (r.dead == kRecMigrate);
-    t.keys_in[i] = active ? (unsigned)tile_of(t, r.cellx - a.x_off, r.celly - a.y_off)
-                          : (unsigned)t.ntiles;
+    const unsigned v = t.info_in[i];
+    const int state = (int)(v >> 30);
+    const bool active = (t.pass == 0) ? (state != kRecDead) : (state == kRecMigrate);
+    t.keys_in[i] = active ? (v & 0x3FFFFFFFu) : (unsigned)t.ntiles;
   }
 }
 
@@ -107,16 +107,18 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
   const unsigned first_inactive = t.tile_offset[t.ntiles];
   const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
   if (j < (unsigned)a.nparticles) {
-    t.rec_out[j] = t.rec_in[t.order[j]];
+    const unsigned src = t.order[j];
+    t.rec_out[j] = t.rec_in[src];
+    t.info_out[j] = t.info_in[src];
   }
 }
 
 /* after the last pass: the ids (positions in rec) of the histories suspended at
  * a collision, for the collision kernel */
 __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs a, TiledArgs t,
-                                                                       const ParticleRec* rec) {
+                                                                       const unsigned* info) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  const bool susp = i < a.nparticles && rec[i].dead == kRecCollide;
+  const bool susp = i < a.nparticles && (info[i] >> 30) == (unsigned)kRecCollide;
   const unsigned long long m = __ballot(susp);
   if (m) {
     unsigned base = 0;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
 
 /* SoA store -> records, in id order */
 __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
-                                                                    int n) {
+                                                                    unsigned* info, int tiles_x,
+                                                                    int x_off, int y_off, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   if (i < n) {
     ParticleRec r;
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
     r.id = (unsigned)i;
     r.dead = p.dead[i];
     rec[i] = r;
+    info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x);
   }
 }
 
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           store_record(h, a, t.rec_out[pid], kRecIdle);
+          t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x);
           has = false;
           did_census = (h.ev == kEvCensus);
         }
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       /* histories handed on: the record carries the state; migrants are counted */
       if (park != kRecIdle) {
         store_record(h, a, t.rec_out[pid], park);
+        t.info_out[pid] = slot_summary(park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x);
         has = false;
       }
       w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
@@ -479,11 +485,11 @@ void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, 
   *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesMin + 1;
 }
 
-hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, int n,
-                                 hipStream_t stream) {
+hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
+                                 int tiles_x, int x_off, int y_off, int n, hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, p, rec, n);
+                       dim3(kSortBlock), 0, stream, p, rec, info, tiles_x, x_off, y_off, n);
   }
   return hipGetLastError();
 }
@@ -558,6 +564,9 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     ParticleRec* swap = t.rec_in; /* this pass's output is the next stage's input */
     t.rec_in = t.rec_out;
     t.rec_out = swap;
+    unsigned* swap_info = t.info_in;
+    t.info_in = t.info_out;
+    t.info_out = swap_info;
 
     unsigned migrants = 0;
     err = hipMemcpyAsync(&migrants, &t.ctrl[kCtrlMigrants], sizeof(unsigned),
@@ -583,7 +592,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   /* 3. the suspended histories: K2 over the collision queue; it counts its
    * events in the second StepCounters record */
   hipLaunchKernelGGL(collect_suspended_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t,
-                     t.rec_in);
+                     t.info_in);
   if (after_collect) {
     (void)hipEventRecord(after_collect, stream);
   }
@@ -592,6 +601,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.queue = t.collide_queue;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
   c.rec = t.rec_in;
+  c.slot_info = t.info_in;
+  c.tiles_x = t.tiles_x;
   return launch_solve(c, kVariantEventSorted, stream);
 }
 
