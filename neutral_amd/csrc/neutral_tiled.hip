@@ -117,19 +117,32 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
  * a collision, for the collision kernel */
 __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs a, TiledArgs t,
                                                                        const unsigned* info) {
+  /* one queue reservation per workgroup: a returning atomic on a single word
+   * takes ~100 ops/us, and every history of a collision-only deck is suspended */
+  __shared__ unsigned s_count[kSortBlock / 64];
+  __shared__ unsigned s_base;
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6;
   const bool susp = i < a.nparticles && (info[i] >> 30) == (unsigned)kRecCollide;
   const unsigned long long m = __ballot(susp);
-  if (m) {
-    unsigned base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if ((int)(threadIdx.x & 63) == leader) {
-      base = atomicAdd(&t.ctrl[kCtrlCollideCount], (unsigned)__popcll(m));
+  if ((threadIdx.x & 63) == 0) {
+    s_count[wave] = (unsigned)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (int w = 0; w < kSortBlock / 64; ++w) {
+      total += s_count[w];
     }
-    base = __shfl(base, leader, 64);
-    if (susp) {
-      t.collide_queue[base + lane_rank(m)] = (unsigned)i;
+    s_base = total ? atomicAdd(&t.ctrl[kCtrlCollideCount], total) : 0u;
+  }
+  __syncthreads();
+  if (susp) {
+    unsigned before = 0;
+    for (int w = 0; w < wave; ++w) {
+      before += s_count[w];
     }
+    t.collide_queue[s_base + before + (unsigned)lane_rank(m)] = (unsigned)i;
   }
 }
 
