@@ -17,16 +17,22 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    """CPU-side artefacts (oracle, host layer) are built on demand; the HIP
-    library is only ever built by __graft_entry__.build()."""
+    """Artefacts missing from a fresh checkout are built on demand (the normal
+    route is __graft_entry__.build()): the oracle, the host layer and -- where
+    hipcc is installed, it cross-compiles without a GPU -- the HIP library."""
+    import shutil
     import subprocess
     oracle = os.path.join(ROOT, "oracle", "liboracle.so")
     hostlib = os.path.join(ROOT, "neutral_amd", "host", "libneutral_host.so")
+    hiplib = os.path.join(ROOT, "neutral_amd", "libneutral_hip.so")
     if not os.path.exists(oracle):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     if not os.path.exists(hostlib):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "neutral_amd"),
                                "host/libneutral_host.so"])
+    if not os.path.exists(hiplib) and (shutil.which("hipcc") or
+                                       os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "neutral_amd"), "all"])
 
 
 _ensure_built()
