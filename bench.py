@@ -186,8 +186,20 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
             r.events.append((res.nprocessed, res.facets, res.collisions, res.census))
         return steps, time.perf_counter() - t0, r
 
-    n0 = 100_000
-    s0, t0, _ = run(n0)
+    # The static partition and the tally atomics of the omp3 scheme do not always
+    # scale to every hardware thread: probe a few thread counts on a small sample
+    # and time the real sample with the fastest, so the baseline is the CPU at
+    # its best.
+    n0 = 200_000
+    best = None
+    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+        ob.lib().orc_set_num_threads(threads)
+        s_, t_, _ = run(n0)
+        if best is None or s_ / t_ > best[0]:
+            best = (s_ / t_, threads, t_)
+    cores = best[1]
+    t0 = best[2]
+    ob.lib().orc_set_num_threads(cores)
     n = int(min(max(n0, n0 * target_seconds / max(t0, 1e-3)), 20_000_000))
     n = max(n0, (n // 1000) * 1000)
     steps, secs, oracle_run = run(n)
