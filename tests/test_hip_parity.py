@@ -495,3 +495,27 @@ def test_full_size_csp_step_properties(iface, make_problem, cs):
     # (collisions in the block during step 2 dominate the tally: ~1 % Monte-Carlo noise at 1e6)
     assert totals[1000000][0] == pytest.approx(totals[100000000][0], rel=3e-2)
     assert totals[1000000][1] == pytest.approx(totals[100000000][1], rel=2e-3)
+
+
+@pytest.mark.parametrize("deck,nx,its", [("csp", 400, 10), ("split", 800, 1), ("scatter", 400, 1),
+                                         ("stream", 400, 1)])
+def test_baseline_shapes_per_cell_tally_l2(iface, make_problem, cs, deck, nx, its):
+    """The BASELINE.json configurations at their mesh sizes with 1e6 particles,
+    default (tiled) pipeline against the oracle: exact per-step event counts and
+    the per-cell tally L2 ("tally L2 vs omp3"), bar 1e-6, asserted at 1e-9."""
+    prob = make_problem(deck, nx=nx, nparticles=1000000, iterations=its)
+    sim = iface.Simulation(prob, *cs, variant=2)
+    ref = ob.OracleRun(prob, *cs)
+    sim.inject()
+    ref.inject()
+    for tt in range(1, its + 1):
+        g, c = sim.step(tt), ref.step(tt)
+        assert (g.nprocessed, g.facets, g.collisions, g.census) == \
+            (c.nprocessed, c.facets, c.collisions, c.census)
+    tg, tc = sim.tally_host(), ref.tally
+    assert np.linalg.norm(tg - tc) / np.linalg.norm(tc) < TALLY_L2_TOL
+    assert np.array_equal(tg == 0.0, tc == 0.0)
+    gp, cp = sim.particle_arrays(), ref.particles.as_dict()
+    for f in ("cellx", "celly", "dead"):
+        assert np.array_equal(gp[f], cp[f]), f
+    sim.close()
