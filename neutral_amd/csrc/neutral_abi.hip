@@ -370,6 +370,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.queue = nullptr;
   a.queue_len = nullptr;
   a.rec = nullptr;
+  a.blocks_per_cu = 0;
   a.slot_info = nullptr;
   a.tiles_x = 0;
 

@@ -108,6 +108,7 @@ struct SolveArgs {
   const unsigned* queue;
   const unsigned* queue_len; /* [device] number of valid entries */
   ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
+  int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU */
   unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
 };

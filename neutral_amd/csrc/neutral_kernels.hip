@@ -523,6 +523,18 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     }
     auto launch = [&](auto kernel) {
       int grid = resident_blocks(kernel);
+      if (a.blocks_per_cu > 0) {
+        /* the caller knows how little work there is: fewer resident waves per
+         * SIMD shorten every history's serial chain (see launch_solve_tiled) */
+        int cus = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        }
+        if (a.blocks_per_cu * cus < grid) {
+          grid = a.blocks_per_cu * cus;
+        }
+      }
       if (grid > want_blocks) {
         grid = want_blocks;
       }

@@ -36,6 +36,7 @@
  * in K1, so particle end states are bit-identical; only the summation order of
  * the tally changes.
  */
+#include <cstdlib>
 #include <cstring> /* before rocprim: its texture iterator calls ::memset on the host */
 
 #include <rocprim/rocprim.hpp>
@@ -610,6 +611,28 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     (void)hipEventRecord(after_collect, stream);
   }
   SolveArgs c = a;
+  {
+    /* A collider is a serial chain of ~10^3 collisions; with few of them the stage
+     * lasts one chain, and a chain runs faster the fewer waves share its SIMD
+     * (csp, per chain: 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two:
+     * profiles/r01f).  So a queue that fits one (two) workgroup(s) per CU gets
+     * exactly that many; anything larger fills the chip as usual. */
+    unsigned queued = 0;
+    hipError_t qe = hipMemcpyAsync(&queued, &t.ctrl[kCtrlCollideCount], sizeof(unsigned),
+                                   hipMemcpyDeviceToHost, stream);
+    if (qe == hipSuccess) {
+      qe = hipStreamSynchronize(stream);
+    }
+    if (qe != hipSuccess) {
+      return qe;
+    }
+    const unsigned lanes_per_block_row = (unsigned)cus * 256u;
+    c.blocks_per_cu = (queued <= lanes_per_block_row) ? 1 : (queued <= 2u * lanes_per_block_row) ? 2 : 0;
+    const char* force = getenv("NEUTRAL_K2_BLOCKS_PER_CU"); /* experiment knob */
+    if (force) {
+      c.blocks_per_cu = atoi(force);
+    }
+  }
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
