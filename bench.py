@@ -297,7 +297,12 @@ def main():
         elapsed = time.perf_counter() - t0
 
         stats = iface.last_step()
-        iface.library().neutral_hip_sync_particles(sim.particles)  # untimed write-back
+        # the deferred write-back of the SoA particle arrays, timed on its own: what
+        # every step would additionally cost a caller that reads those arrays
+        t_wb = time.perf_counter()
+        iface.library().neutral_hip_sync_particles(sim.particles)
+        torch.cuda.synchronize()
+        writeback_ms = 1e3 * (time.perf_counter() - t_wb)
         tot = torch.tensor([sum(r.facets for r in results), sum(r.collisions for r in results),
                             sum(r.census for r in results), sum(r.nprocessed for r in results)],
                            dtype=torch.float64, device=sim.device)
@@ -337,6 +342,12 @@ def main():
                 "events": {"facets": facets, "collisions": collisions, "census": census,
                            "histories": histories},
                 "global_tally": float(global_tally.sum().item()),
+                "particle_writeback": {
+                    "mode": "deferred (neutral_hip_set_lazy_export): nothing reads the SoA "
+                            "particle arrays between timesteps; written back once after the run",
+                    "ms_per_writeback": writeback_ms,
+                    "value_if_written_back_every_step":
+                        particle_steps / (elapsed + K * writeback_ms * 1e-3)},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": measured_traffic(deck, nx, ntotal, int(stats.variant),

@@ -207,8 +207,9 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
  * Safe to call with any (or no) store in hand: the owner's arrays are remembered. */
 void sync_soa() {
   if (!g.soa_valid && g.rec_valid && g.rec_owner) {
-    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.rec_owner_view, g.rec_count,
-                                             g.stream));
+    /* order[] is free between solves: scratch for the inverse permutation */
+    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.order, g.rec_owner_view,
+                                             g.rec_count, g.stream));
     HIP_CHECK(hipStreamSynchronize(g.stream));
   }
   g.soa_valid = true;

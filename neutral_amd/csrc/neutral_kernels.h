@@ -161,8 +161,9 @@ size_t tiled_sort_temp_bytes(int nparticles, int ntiles);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
                                  int tiles_x, int x_off, int y_off, int n, hipStream_t stream);
-hipError_t launch_export_records(const ParticleRec* rec, const ParticleView& p, int n,
-                                 hipStream_t stream);
+/* slot_of_id: nparticles words of scratch (the sort's order[] array serves) */
+hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
+                                 const ParticleView& p, int n, hipStream_t stream);
 void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
 /* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
  * collision kernel.  The optional events are recorded after the first sort,
