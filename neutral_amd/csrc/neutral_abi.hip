@@ -169,7 +169,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   neutral::TiledArgs& t = g.tiled;
   if (nparticles > g.tiled_particles || tx * ty > g.tiled_tiles) {
     void* old[] = {t.order,     t.collide_queue, t.keys_in, t.keys_out, t.sort_temp,
-                   t.tile_offset, t.rec_in,      t.rec_out, t.info_in,  t.info_out};
+                   t.tile_offset, t.rec_in,      t.rec_out, t.info_in,  t.info_out,
+                   t.susp};
     g.rec_valid = false;
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
@@ -183,6 +184,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
     HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
     t.sort_temp_bytes = neutral::tiled_sort_temp_bytes(nparticles, tx * ty);
     HIP_CHECK(hipMalloc(&t.sort_temp, t.sort_temp_bytes ? t.sort_temp_bytes : 16));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty + 2)));
@@ -374,6 +376,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.blocks_per_cu = 0;
   a.slot_info = nullptr;
   a.tiles_x = 0;
+  a.susp = nullptr;
 
   HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
   const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);

@@ -40,6 +40,16 @@ struct alignas(16) ParticleRec {
 };
 static_assert(sizeof(ParticleRec) == 80, "ParticleRec must stay 80 bytes");
 
+/* What a history suspended MID-CHAIN by the collision stage's time slicing needs
+ * beyond its record: the RNG counter, the deposition not yet tallied
+ * (omp3/neutral.c:236: flushed only at a facet, the census or death) and the
+ * watchdog count.  Indexed like the record array. */
+struct alignas(16) SuspendExtra {
+  double energy_deposition;
+  unsigned counter;
+  unsigned nevents;
+};
+
 struct InjectArgs {
   int nparticles;
   uint64_t pid_base;
@@ -111,6 +121,7 @@ struct SolveArgs {
   int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU */
   unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
+  SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
 };
 
 /* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
@@ -130,6 +141,7 @@ struct TiledArgs {
   unsigned* tile_offset;   /* ntiles + 2: first sorted position of each key */
   uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
+  SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants */
   int chunk_particles;     /* particles one workgroup takes at a time */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */

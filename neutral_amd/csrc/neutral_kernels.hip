@@ -184,6 +184,36 @@ constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many 
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
+/* ---- time slicing of the collision stage (queue mode) ---------------------------
+ * A collider is a serial chain (csp: 931 collisions, 2.4-4.9 ms depending on how
+ * many waves share its SIMD), and chains of one deck are about equally long.
+ * Handing ids out first-come-first-served therefore runs in GENERATIONS: with
+ * 1.5 histories per lane the second generation occupies every wave at half its
+ * lanes for another full chain (9.8 ms where the work is worth 7.3).  So when
+ * the queue is short enough for it, every wave takes an equal, strided share of
+ * the queue into a ring in LDS and ROUND-ROBINS its lanes over the share: every
+ * kSlicePasses collision passes the colliding lanes put their histories at the
+ * back of the ring (record + SuspendExtra) and take the ones at the front, as
+ * long as any are waiting.  All histories of a wave then finish within one
+ * slice of each other, every lane stays busy until then, and no wave depends on
+ * another (no in-launch hand-off between waves, nothing to wait for).
+ * A swap costs a record store/load and resume() -- about a fifth of a collision
+ * every kSlicePasses collisions.  Histories execute exactly the events they
+ * would execute unsliced: the record, the RNG counter and the pending
+ * deposition are all that survives a loop head (see resume()). */
+constexpr int kPoolCap = 1024; /* ring entries per wave (power of two) */
+#ifndef NEUTRAL_SLICE_PASSES
+#define NEUTRAL_SLICE_PASSES 64
+#endif
+constexpr int kSlicePasses = NEUTRAL_SLICE_PASSES;
+constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is valid */
+
+__device__ __forceinline__ void wave_lds_sync() {
+  /* LDS operations of one wave execute in order; this only pins the compiler */
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 /* final state of a history: into the SoA store, or into its record in queue mode */
 template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
@@ -228,6 +258,15 @@ void history_regroup_kernel(SolveArgs a) {
     }
     __syncthreads();
   }
+  /* this wave's ring, behind the index(es); queue mode only */
+  unsigned* ring = nullptr;
+  if (kQueue) {
+    int idx_entries = a.scatter_index ? a.scatter_index_n + 1 : 0;
+    if (!kSameTables && a.absorb_index) {
+      idx_entries += a.absorb_index_n + 1;
+    }
+    ring = (unsigned*)(lds_index + ((idx_entries + 7) & ~7)) + (threadIdx.x >> 6) * kPoolCap;
+  }
 
   const GlobalTally tally;
   /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
@@ -250,6 +289,22 @@ void history_regroup_kernel(SolveArgs a) {
   int cur = 0;
   int end = 0;
   bool drained = false;
+
+  /* pooled mode: the wave's strided share of the queue goes into its ring */
+  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolCap);
+  unsigned ring_head = 0; /* wave-uniform, free-running; entry i lives at i & (kPoolCap-1) */
+  unsigned ring_tail = 0;
+  int slice = 0;
+  if (pooled) {
+    const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
+    const int share = (gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
+    for (int k = (int)(threadIdx.x & 63); k < share; k += 64) {
+      ring[k] = a.queue[gw + k * nwaves];
+    }
+    ring_tail = (unsigned)share;
+    drained = (share == 0);
+    wave_lds_sync();
+  }
 
   for (;;) {
     const unsigned long long m_refill = __ballot(want == kWantRefill);
@@ -279,7 +334,28 @@ void history_regroup_kernel(SolveArgs a) {
       pass = kWantCollide;
     }
 
-    if (pass == kWantRefill) {
+    if (pass == kWantRefill && pooled) {
+      /* ---- REFILL pass, pooled: the histories at the front of the ring ---- */
+      const int avail = (int)(ring_tail - ring_head);
+      const int n_take = (n_refill < avail) ? n_refill : avail;
+      const int rank = lane_rank(m_refill);
+      if (want == kWantRefill && rank < n_take) {
+        const unsigned e = ring[(ring_head + (unsigned)rank) & (kPoolCap - 1)];
+        pid = (int)(e & ~kRequeued);
+        load_record(h, a, a.rec[pid]);
+        resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
+        if (e & kRequeued) {
+          const SuspendExtra x = a.susp[pid];
+          h.energy_deposition = x.energy_deposition;
+          h.counter = x.counter;
+          h.nevents = x.nevents;
+        }
+        decide(h, a);
+        want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+      }
+      ring_head += (unsigned)n_take;
+      drained = (ring_head == ring_tail);
+    } else if (pass == kWantRefill) {
       /* ---- REFILL pass: hand fresh particle ids to the empty lanes ---- */
       if (cur >= end) {
         int base = 0;
@@ -332,6 +408,28 @@ void history_regroup_kernel(SolveArgs a) {
           decide(h, a);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
+      }
+      if (pooled && ++slice >= kSlicePasses && ring_head != ring_tail) {
+        /* ---- end of a time slice: colliders swap with the waiting histories ---- */
+        slice = 0;
+        const bool out = (want == kWantCollide);
+        const unsigned long long m_out = __ballot(out);
+        if (out) {
+          store_record(h, a, a.rec[pid], kRecCollide);
+          SuspendExtra x;
+          x.energy_deposition = h.energy_deposition;
+          x.counter = h.counter;
+          x.nevents = h.nevents;
+          a.susp[pid] = x;
+          ring[(ring_tail + (unsigned)lane_rank(m_out)) & (kPoolCap - 1)] = (unsigned)pid | kRequeued;
+          want = kWantRefill;
+        }
+        ring_tail += (unsigned)__popcll(m_out);
+        drained = false;
+        /* the same wave reads these records back later, possibly from another
+         * lane: stores complete (workgroup scope: same CU, same L1) first */
+        __threadfence_block();
+        wave_lds_sync();
       }
     } else {
       /* ---- STREAM pass: facet crossings, census, end of history ---- */
@@ -517,9 +615,15 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
      * the worst case, surplus waves drain at their first refill */
     const int chunks = (a.nparticles + kQueueChunk - 1) / kQueueChunk;
     const int want_blocks = (chunks + (kBlock / 64) - 1) / (kBlock / 64);
-    size_t lds = a.scatter_index ? sizeof(unsigned short) * (a.scatter_index_n + 1) : 0;
+    size_t idx_entries = a.scatter_index ? (size_t)(a.scatter_index_n + 1) : 0;
     if (!a.same_tables && a.absorb_index) {
-      lds += sizeof(unsigned short) * (a.absorb_index_n + 1);
+      idx_entries += (size_t)(a.absorb_index_n + 1);
+    }
+    size_t lds = sizeof(unsigned short) * idx_entries;
+    if (a.queue) {
+      /* one ring per wave behind the index(es), see history_regroup_kernel */
+      lds = sizeof(unsigned short) * ((idx_entries + 7) & ~(size_t)7) +
+            sizeof(unsigned) * (size_t)kPoolCap * (kBlock / 64);
     }
     auto launch = [&](auto kernel) {
       int grid = resident_blocks(kernel);

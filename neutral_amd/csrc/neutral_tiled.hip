@@ -653,6 +653,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.rec = t.rec_in;
   c.slot_info = t.info_in;
   c.tiles_x = t.tiles_x;
+  c.susp = t.susp;
   return launch_solve(c, kVariantEventSorted, stream);
 }
 
