@@ -167,6 +167,9 @@ typedef struct {
                            timestep; 0 for every sane input) */
   int stream_passes;    /* streaming passes the step took (1 unless particles outran
                            the LDS tally window and migrated to another tile) */
+  uint64_t requeued;    /* tiled variant: times the collision stage put a history back in
+                           its wave's ring at the end of a time slice (0 when every
+                           wave's share of the collision queue fitted its lanes) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

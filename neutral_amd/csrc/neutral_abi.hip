@@ -374,6 +374,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.queue_len = nullptr;
   a.rec = nullptr;
   a.blocks_per_cu = 0;
+  a.max_blocks = 0;
   a.slot_info = nullptr;
   a.tiles_x = 0;
   a.susp = nullptr;
@@ -498,6 +499,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                     "were stopped.\n", (unsigned long long)g.last.aborted);
   }
   g.last.stream_passes = tiled ? g.last_passes : 0;
+  g.last.requeued = tiled ? hc[1].nrequeued : 0;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

@@ -77,6 +77,7 @@ struct StepCounters {
   unsigned long long ncensus; /* histories that ended in a census event */
   unsigned int queue_head;    /* K2: next unclaimed particle index */
   unsigned int aborted;       /* histories stopped by the event watchdog (should be 0) */
+  unsigned long long nrequeued; /* time-slice swaps of the collision stage (queue mode) */
 };
 
 struct SolveArgs {
@@ -119,6 +120,7 @@ struct SolveArgs {
   const unsigned* queue_len; /* [device] number of valid entries */
   ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
   int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU */
+  int max_blocks;            /* > 0: cap on the regroup kernel's grid (test knob) */
   unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */

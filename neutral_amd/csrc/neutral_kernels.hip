@@ -295,6 +295,7 @@ void history_regroup_kernel(SolveArgs a) {
   unsigned ring_head = 0; /* wave-uniform, free-running; entry i lives at i & (kPoolCap-1) */
   unsigned ring_tail = 0;
   int slice = 0;
+  unsigned w_requeued = 0;
   if (pooled) {
     const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
     const int share = (gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
@@ -425,6 +426,7 @@ void history_regroup_kernel(SolveArgs a) {
           want = kWantRefill;
         }
         ring_tail += (unsigned)__popcll(m_out);
+        w_requeued += (unsigned)__popcll(m_out);
         drained = false;
         /* the same wave reads these records back later, possibly from another
          * lane: stores complete (workgroup scope: same CU, same L1) first */
@@ -451,6 +453,9 @@ void history_regroup_kernel(SolveArgs a) {
     }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
+  if (w_requeued && (threadIdx.x & 63) == 0) {
+    atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
+  }
 }
 
 /* ---- bucketed cs index -------------------------------------------------------- */
@@ -641,6 +646,9 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       }
       if (grid > want_blocks) {
         grid = want_blocks;
+      }
+      if (a.max_blocks > 0 && grid > a.max_blocks) {
+        grid = a.max_blocks;
       }
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
     };

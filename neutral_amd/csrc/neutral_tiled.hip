@@ -646,6 +646,10 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     if (force) {
       c.blocks_per_cu = atoi(force);
     }
+    /* test knob: a small grid makes the collision stage time-slice (shares larger
+     * than a wave) at particle counts a CPU oracle can follow */
+    const char* max_blocks = getenv("NEUTRAL_K2_MAX_BLOCKS");
+    c.max_blocks = max_blocks ? atoi(max_blocks) : 0;
   }
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;

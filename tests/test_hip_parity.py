@@ -422,6 +422,56 @@ def test_kernel_variants_are_bitwise_identical_in_particle_state(iface, make_pro
         assert np.linalg.norm(t0 - t1) / np.linalg.norm(t0) < 1e-13
 
 
+@pytest.mark.parametrize("deck,nx,n,dt,its,blocks", [("scatter", 64, 40000, None, 1, 32),
+                                                     ("csp", 100, 100000, 1.0e-6, 2, 4),
+                                                     ("split", 200, 100000, 2.0e-7, 2, 32)])
+def test_collision_stage_time_slicing_is_bitwise_neutral(iface, make_problem, cs, monkeypatch,
+                                                         deck, nx, n, dt, its, blocks):
+    """With more queued colliders than lanes the collision stage round-robins each
+    wave's share through an LDS ring (histories are suspended mid-chain and resumed,
+    possibly on another lane).  A grid of a few workgroups makes that happen at a size the
+    oracle finishes in seconds: same particle bits as the over-particle kernel, same
+    event counts as the oracle, and the swaps really took place."""
+    kw = dict(nx=nx, nparticles=n, iterations=its)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    monkeypatch.setenv("NEUTRAL_K2_MAX_BLOCKS", str(blocks))
+    sim = iface.Simulation(prob, *cs, variant=2)
+    sim.inject()
+    ev2, requeued, suspended = [], 0, 0
+    for tt in range(1, its + 1):
+        r = sim.step(tt)
+        ev2.append((r.nprocessed, r.facets, r.collisions, r.census))
+        requeued += iface.last_step().requeued
+        suspended += iface.last_step().suspended
+        assert iface.last_step().aborted == 0
+    p2, t2 = sim.particle_arrays(), sim.tally_host()
+    sim.close()
+    monkeypatch.delenv("NEUTRAL_K2_MAX_BLOCKS")
+    assert requeued > 0, f"the case no longer exercises time slicing ({suspended} colliders)"
+
+    sim = iface.Simulation(prob, *cs, variant=0)
+    sim.inject()
+    ev0 = []
+    for tt in range(1, its + 1):
+        r = sim.step(tt)
+        ev0.append((r.nprocessed, r.facets, r.collisions, r.census))
+    p0, t0 = sim.particle_arrays(), sim.tally_host()
+    sim.close()
+    assert ev0 == ev2
+    for f in p0:
+        assert np.array_equal(p0[f], p2[f]), f
+    assert np.linalg.norm(t0 - t2) / np.linalg.norm(t0) < 1e-13
+
+    ref = ob.OracleRun(prob, *cs)
+    ref.inject()
+    for tt in range(1, its + 1):
+        c = ref.step(tt)
+        assert (c.nprocessed, c.facets, c.collisions) == ev2[tt - 1][:3]
+    assert np.linalg.norm(t2 - ref.tally) / np.linalg.norm(ref.tally) < TALLY_L2_TOL
+
+
 def test_tiled_variant_lazy_export_and_variant_switches(iface, make_problem, cs):
     """The tiled variant's private record store and the SoA arrays stay coherent:
     lazy export + explicit sync, switching variants between steps, reinjection."""
