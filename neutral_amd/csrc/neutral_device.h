@@ -32,9 +32,27 @@ constexpr double kOpenBoundCorrection = 1.0e-13;
 
 /* ---- Threefry2x64-20 (Random123/threefry.h:190-293, 20 rounds :179) ------ */
 
+/* 64-bit rotate as two 32-bit funnel shifts (v_alignbit_b32, full rate): the
+ * generic (v << N) | (v >> (64 - N)) becomes 64-bit shifts plus ORs, four to
+ * five instructions per rotate, and a Threefry call has twenty of them. */
 template <unsigned N>
 __device__ __forceinline__ uint64_t rotl64(uint64_t v) {
-  return (v << N) | (v >> (64 - N));
+  static_assert(N > 0 && N < 64, "rotation out of range");
+  const uint32_t lo = (uint32_t)v;
+  const uint32_t hi = (uint32_t)(v >> 32);
+  uint32_t nlo, nhi;
+  if (N == 32) {
+    nlo = hi;
+    nhi = lo;
+  } else if (N < 32) {
+    /* alignbit(a, b, s) = low 32 bits of ({a,b} >> s) */
+    nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - N);
+    nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - N);
+  } else {
+    nhi = __builtin_amdgcn_alignbit(lo, hi, 64 - N);
+    nlo = __builtin_amdgcn_alignbit(hi, lo, 64 - N);
+  }
+  return ((uint64_t)nhi << 32) | nlo;
 }
 
 #define NEUTRAL_TF_ROUND(R) \

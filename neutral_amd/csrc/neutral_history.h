@@ -145,12 +145,32 @@ __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<Ind
   }
 }
 
-__device__ __forceinline__ void macroscopic_from_density(History& h) {
-  /* omp3/neutral.c:112-116, :289-291, :375-377, and the loop head's :135 */
-  h.number_density = (h.local_density * kAvogadros / kMolarMass);
+/* macroscopic cross sections from number_density and the microscopic ones
+ * (omp3/neutral.c:114-116, :290-291, :376-377) and the loop head's :135 */
+__device__ __forceinline__ void macroscopic_from_micro(History& h) {
   h.macro_s = h.number_density * h.micro_s * kBarns;
   h.macro_a = h.number_density * h.micro_a * kBarns;
   h.cell_mfp = 1.0 / (h.macro_s + h.macro_a);
+}
+
+__device__ __forceinline__ void macroscopic_from_density(History& h) {
+  /* omp3/neutral.c:112-113, :289, :375.  A collision re-evaluates this quotient
+   * from an unchanged density (:289): same operands, same bits, so collide()
+   * keeps the value and calls macroscopic_from_micro() alone. */
+  h.number_density = (h.local_density * kAvogadros / kMolarMass);
+  macroscopic_from_micro(h);
+}
+
+/* x / (x + x) for two bit-identical operands, as p_absorb (omp3/neutral.c:224)
+ * and the absorbed fraction (:481-482) become when both cs tables hold the same
+ * data: x + x is exact and the quotient is exactly one half unless x is zero,
+ * infinite or NaN, or the sum overflows -- those go through the division. */
+__device__ __forceinline__ double half_or_quotient(double x, double sum) {
+  if (__builtin_expect(sum != 0.0 && fabs(sum) < __builtin_huge_val(), 1)) {
+    return 0.5;
+  }
+  asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+  return x / sum;
 }
 
 /* omp3/neutral.c:435-436 */
@@ -161,15 +181,18 @@ __device__ __forceinline__ void refresh_direction(History& h) {
 
 /* the energy- and table-dependent factors of calculate_energy_deposition
  * (omp3/neutral.c:481-494); deposit() below finishes the product */
+template <bool kSameTables>
 __device__ __forceinline__ void refresh_deposition_terms(History& h) {
   const double microscopic_cs_total = h.micro_s + h.micro_a;
   constexpr double average_exit_energy_absorb = 0.0;
-  const double absorption_heating =
-      (h.micro_a / microscopic_cs_total) * average_exit_energy_absorb;
+  /* identical tables: micro_s and micro_a are the same bits (lookup_cs) */
+  const double absorbed_fraction = kSameTables
+                                       ? half_or_quotient(h.micro_a, microscopic_cs_total)
+                                       : (h.micro_a / microscopic_cs_total);
+  const double absorption_heating = absorbed_fraction * average_exit_energy_absorb;
   const double average_exit_energy_scatter =
       h.energy * ((kMassNo * kMassNo + kMassNo + 1) / ((kMassNo + 1) * (kMassNo + 1)));
-  const double scattering_heating =
-      (1.0 - (h.micro_a / microscopic_cs_total)) * average_exit_energy_scatter;
+  const double scattering_heating = (1.0 - absorbed_fraction) * average_exit_energy_scatter;
   h.dep_heat = (h.energy - scattering_heating - absorption_heating);
   h.dep_sigma = (microscopic_cs_total * kBarns);
 }
@@ -272,7 +295,7 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   h.mfp_to_collision = -log(rn0) / h.macro_s;
   refresh_direction(h);
-  refresh_deposition_terms(h);
+  refresh_deposition_terms<kSameTables>(h);
 }
 
 /* Re-derives the locals of a history that another kernel suspended at a loop
@@ -294,7 +317,7 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   h.counter = 1;
   h.nevents = 0;
   refresh_direction(h);
-  refresh_deposition_terms(h);
+  refresh_deposition_terms<kSameTables>(h);
 }
 
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
@@ -337,7 +360,9 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   h.x += distance_to_collision * h.omega_x;
   h.y += distance_to_collision * h.omega_y;
 
-  const double p_absorb = h.macro_a / (h.macro_s + h.macro_a);
+  /* identical tables: macro_s and macro_a are the same bits (macroscopic_from_micro) */
+  const double p_absorb = kSameTables ? half_or_quotient(h.macro_a, h.macro_s + h.macro_a)
+                                      : h.macro_a / (h.macro_s + h.macro_a);
   double rc0, rc1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
 
@@ -366,7 +391,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   }
 
   lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
-  macroscopic_from_density(h);
+  macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
 
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
@@ -374,7 +399,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);
   refresh_direction(h);
-  refresh_deposition_terms(h);
+  refresh_deposition_terms<kSameTables>(h);
   return false;
 }
 
