@@ -334,9 +334,17 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
   const int ex = h.cellx - a.x_off + a.pad;
   const int ey = h.celly - a.y_off + a.pad;
   double distance_to_facet;
+#if defined(NEUTRAL_EXP_COMPUTED_EDGES)
+  /* timing experiment only: no edge loads */
+  const double ew = 1.0 / (double)a.nx;
+  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
+                         ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew,
+                         distance_to_facet, h.x_facet);
+#else
   calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
                          a.edgex[ex], a.edgex[ex + 1], a.edgey[ey], a.edgey[ey + 1],
                          distance_to_facet, h.x_facet);
+#endif
   const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
   const double distance_to_census = h.speed * h.dt_to_census;
   if (distance_to_collision < distance_to_facet && distance_to_collision < distance_to_census) {
@@ -403,9 +411,56 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   return false;
 }
 
-/* facet_event, omp3/neutral.c:303-380 */
+/* facet_event, omp3/neutral.c:303-380.
+ *
+ * Written load-first: the neighbour cell (:333-369, integer work) is worked out
+ * before the floating-point updates (:311-330) so that the density load of the
+ * new cell (:372) is in flight while they execute -- issued after them it is a
+ * dependent L2 round trip per facet (14 % of the stream kernel,
+ * profiles/r02/ablate_facetloads.log).  Every value is computed from the same
+ * operands as in the reference's order: the position update uses the direction
+ * BEFORE a reflection, as :329-330 precede :333. */
 template <typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
+  /* step to the neighbour cell, or reflect at the outer boundary */
+  int ncellx = h.cellx;
+  int ncelly = h.celly;
+  bool reflect = false;
+  if (h.x_facet) {
+    if (h.omega_x > 0.0) {
+      if (h.cellx >= (a.global_nx - 1)) {
+        reflect = true;
+      } else {
+        ncellx++;
+      }
+    } else if (h.omega_x < 0.0) {
+      if (h.cellx <= 0) {
+        reflect = true;
+      } else {
+        ncellx--;
+      }
+    }
+  } else {
+    if (h.omega_y > 0.0) {
+      if (h.celly >= (a.global_ny - 1)) {
+        reflect = true;
+      } else {
+        ncelly++;
+      }
+    } else if (h.omega_y < 0.0) {
+      if (h.celly <= 0) {
+        reflect = true;
+      } else {
+        ncelly--;
+      }
+    }
+  }
+#if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
+  const double new_density = h.local_density; /* timing experiment only (uniform decks) */
+#else
+  const double new_density = a.density[(ncelly - a.y_off) * a.nx + (ncellx - a.x_off)];
+#endif
+
   const double distance_to_facet = h.distance;
   h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
   h.dt_to_census -= (distance_to_facet / h.speed);
@@ -416,42 +471,20 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   h.x += distance_to_facet * h.omega_x;
   h.y += distance_to_facet * h.omega_y;
 
-  /* step to the neighbour cell, or reflect at the outer boundary */
-  if (h.x_facet) {
-    if (h.omega_x > 0.0) {
-      if (h.cellx >= (a.global_nx - 1)) {
-        h.omega_x = -h.omega_x;
-        h.u_x_inv = 1.0 / (h.omega_x * h.speed);
-      } else {
-        h.cellx++;
-      }
-    } else if (h.omega_x < 0.0) {
-      if (h.cellx <= 0) {
-        h.omega_x = -h.omega_x;
-        h.u_x_inv = 1.0 / (h.omega_x * h.speed);
-      } else {
-        h.cellx--;
-      }
-    }
-  } else {
-    if (h.omega_y > 0.0) {
-      if (h.celly >= (a.global_ny - 1)) {
-        h.omega_y = -h.omega_y;
-        h.u_y_inv = 1.0 / (h.omega_y * h.speed);
-      } else {
-        h.celly++;
-      }
-    } else if (h.omega_y < 0.0) {
-      if (h.celly <= 0) {
-        h.omega_y = -h.omega_y;
-        h.u_y_inv = 1.0 / (h.omega_y * h.speed);
-      } else {
-        h.celly--;
-      }
+  if (reflect) {
+    /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
+     * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
+    if (h.x_facet) {
+      h.omega_x = -h.omega_x;
+      h.u_x_inv = -h.u_x_inv;
+    } else {
+      h.omega_y = -h.omega_y;
+      h.u_y_inv = -h.u_y_inv;
     }
   }
+  h.cellx = ncellx;
+  h.celly = ncelly;
 
-  const double new_density = a.density[(h.celly - a.y_off) * a.nx + (h.cellx - a.x_off)];
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
     macroscopic_from_density(h);

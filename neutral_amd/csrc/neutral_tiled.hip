@@ -52,7 +52,10 @@ namespace neutral {
 constexpr int kTile = kTileCells;                  /* cells per tile edge (16) */
 constexpr int kWindow = 128;                       /* cells per LDS window edge */
 constexpr int kMargin = (kWindow - kTile) / 2;     /* window reach beyond the tile */
-constexpr int kStreamBlock = 1024;                 /* 16 waves share one window */
+#ifndef NEUTRAL_STREAM_BLOCK
+#define NEUTRAL_STREAM_BLOCK 1024
+#endif
+constexpr int kStreamBlock = NEUTRAL_STREAM_BLOCK; /* 16 waves share one window */
 /* A chunk is what one workgroup takes at a time from one tile's particles: big
  * enough to amortise its two barriers and a window move, small enough that
  * every workgroup gets several (the host picks the size from the particle
