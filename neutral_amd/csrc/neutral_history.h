@@ -320,8 +320,21 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   refresh_deposition_terms<kSameTables>(h);
 }
 
-/* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far */
-__device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
+/* the four mesh edges around a cell (omp3/neutral.c:438-447 reads them per event) */
+struct CellEdges {
+  double x_lo, x_hi, y_lo, y_hi;
+};
+
+__device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, int celly) {
+  const int ex = cellx - a.x_off + a.pad;
+  const int ey = celly - a.y_off + a.pad;
+  return CellEdges{a.edgex[ex], a.edgex[ex + 1], a.edgey[ey], a.edgey[ey + 1]};
+}
+
+/* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far.
+ * `e` holds the edges of the history's cell: a collision leaves the cell alone, so
+ * the collision kernel loads them once per cell instead of once per event. */
+__device__ __forceinline__ void decide(History& h, const SolveArgs& a, const CellEdges& e) {
   if (!(h.dt_to_census > 0.0)) {
     h.ev = kEvEnd;
     return;
@@ -331,20 +344,9 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
     h.ev = kEvEnd;
     return;
   }
-  const int ex = h.cellx - a.x_off + a.pad;
-  const int ey = h.celly - a.y_off + a.pad;
   double distance_to_facet;
-#if defined(NEUTRAL_EXP_COMPUTED_EDGES)
-  /* timing experiment only: no edge loads */
-  const double ew = 1.0 / (double)a.nx;
   calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
-                         ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew,
-                         distance_to_facet, h.x_facet);
-#else
-  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
-                         a.edgex[ex], a.edgex[ex + 1], a.edgey[ey], a.edgey[ey + 1],
-                         distance_to_facet, h.x_facet);
-#endif
+                         e.x_lo, e.x_hi, e.y_lo, e.y_hi, distance_to_facet, h.x_facet);
   const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
   const double distance_to_census = h.speed * h.dt_to_census;
   if (distance_to_collision < distance_to_facet && distance_to_collision < distance_to_census) {
@@ -357,6 +359,18 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
     h.ev = kEvCensus;
     h.distance = distance_to_census;
   }
+}
+
+__device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
+#if defined(NEUTRAL_EXP_COMPUTED_EDGES)
+  /* timing experiment only: no edge loads */
+  const double ew = 1.0 / (double)a.nx;
+  const int ex = h.cellx - a.x_off + a.pad;
+  const int ey = h.celly - a.y_off + a.pad;
+  decide(h, a, CellEdges{ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew});
+#else
+  decide(h, a, load_edges(a, h.cellx, h.celly));
+#endif
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
@@ -484,6 +498,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   }
   h.cellx = ncellx;
   h.celly = ncelly;
+
+  /* pin the two quotients above the wait for the density: left alone, the compiler
+   * sinks both divides below the branch that consumes the load */
+  asm volatile("" : "+v"(h.mfp_to_collision), "+v"(h.dt_to_census));
 
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;

@@ -284,6 +284,19 @@ void history_regroup_kernel(SolveArgs a) {
   int pid = -1;
   int want = kWantRefill;
   h.ev = kEvEnd;
+  /* Queue mode (colliders only, VGPRs to spare at 3 waves/SIMD): the edges of the
+   * history's cell stay in registers from one collision to the next. */
+  CellEdges edges{0.0, 0.0, 0.0, 0.0};
+  auto next_event = [&](bool cell_changed) {
+    if (kQueue) {
+      if (cell_changed) {
+        edges = load_edges(a, h.cellx, h.celly);
+      }
+      decide(h, a, edges);
+    } else {
+      decide(h, a);
+    }
+  };
 
   /* wave-private slice of the particle queue (wave-uniform values) */
   int cur = 0;
@@ -351,7 +364,7 @@ void history_regroup_kernel(SolveArgs a) {
           h.counter = x.counter;
           h.nevents = x.nevents;
         }
-        decide(h, a);
+        next_event(true);
         want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
       }
       ring_head += (unsigned)n_take;
@@ -394,7 +407,7 @@ void history_regroup_kernel(SolveArgs a) {
           take = false;
         }
         if (take) {
-          decide(h, a);
+          next_event(true);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
       }
@@ -406,7 +419,7 @@ void history_regroup_kernel(SolveArgs a) {
           put_back<kQueue>(h, a, pid);
           want = kWantRefill;
         } else {
-          decide(h, a);
+          next_event(false);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
       }
@@ -439,7 +452,7 @@ void history_regroup_kernel(SolveArgs a) {
         if (h.ev == kEvFacet) {
           nfacets++;
           cross_facet(h, a, tally);
-          decide(h, a);
+          next_event(true);
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         } else {
           if (h.ev == kEvCensus) {
