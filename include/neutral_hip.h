@@ -237,6 +237,11 @@ void neutral_hip_probe_cs_lookup(const NeutralHipCrossSection* cs, const double*
                                  double* value, int* index, int n, int use_index);
 void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, int* x_facet,
                                          int n);
+/*   division:  in2 = n rows {a, b}; out2 = n rows {a / b as the compiler divides,
+ *              the quotient through the kept reciprocal of b (the stream kernel's
+ *              form of omp3/neutral.c:311-312)}; plain[i] = 1 when both operands lie
+ *              in the range where the kernel uses the second form */
+void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int n);
 /* Library/ABI version, bumped on any signature change. */
 int neutral_hip_abi_version(void);
 

@@ -796,6 +796,16 @@ void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, in
   HIP_CHECK(hipFree(d_in));
 }
 
+void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int n) {
+  double* d_in = stage_in(in2, (size_t)2 * n);
+  double* d_out = stage_in((const double*)nullptr, (size_t)2 * n);
+  int* d_p = stage_in((const int*)nullptr, (size_t)n);
+  HIP_CHECK(neutral::launch_probe_division(d_in, d_out, d_p, n, g.stream));
+  stage_out(out2, d_out, (size_t)2 * n);
+  stage_out(plain, d_p, (size_t)n);
+  HIP_CHECK(hipFree(d_in));
+}
+
 void neutral_hip_synchronize(void) { HIP_CHECK(hipStreamSynchronize(g.stream)); }
 int neutral_hip_abi_version(void) { return NEUTRAL_ABI_VERSION; }
 

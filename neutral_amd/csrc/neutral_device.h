@@ -178,6 +178,40 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
   return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
 }
 
+/* ---- quotients by a denominator that many numerators share --------------------
+ * A facet crossing divides its path length by the speed and by the mean free
+ * path of the cell (omp3/neutral.c:311-312), and neither changes from one vacuum
+ * cell to the next.  IEEE division on this hardware is the sequence
+ *     r0 = rcp(b); two Newton steps -> r; q0 = a*r; q = fma(fma(-b,q0,a), r, q0)
+ * wrapped in v_div_scale / v_div_fmas / v_div_fixup, which only act when an
+ * operand or the quotient comes near the ends of the exponent range or is
+ * special.  For operands inside [2^-300, 2^300] they are the identity, so the
+ * refined reciprocal r -- five of the eleven instructions and the only
+ * quarter-rate one -- depends on b alone and can be kept; the three remaining
+ * operations reproduce `a / b` bit for bit (tested against the compiler's own
+ * division on the device, tests/test_hip_parity.py).  Anything outside the range
+ * takes the ordinary division. */
+__device__ __forceinline__ double refined_reciprocal(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+/* |v| in [2^-300, 2^300): no scaling, no special case in the division of two such */
+__device__ __forceinline__ bool in_plain_division_range(double v) {
+  const unsigned hi = (unsigned)__double2hiint(v) & 0x7FFFFFFFu;
+  return (hi - (723u << 20)) < (600u << 20);
+}
+
+__device__ __forceinline__ double quotient_by_reciprocal(double a, double b, double r) {
+  const double q0 = a * r;
+  const double rem = __builtin_fma(-b, q0, a);
+  return __builtin_fma(rem, r, q0);
+}
+
 /* ---- geometry (omp3/neutral.c:423-471) ------------------------------------- */
 
 __device__ __forceinline__ void calc_distance_to_facet(

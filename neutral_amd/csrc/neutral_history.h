@@ -50,6 +50,10 @@ struct History {
    *   cell_mfp           1/(macro_s+macro_a)              :135
    *   dep_sigma/dep_heat factors of the heating estimator :481-494 */
   double u_x_inv, u_y_inv, dep_sigma, dep_heat;
+  /* stream kernel only (see refined_reciprocal): reciprocals of speed and cell_mfp
+   * for the two quotients of a facet crossing, and whether each may be used */
+  double r_speed, r_cell_mfp;
+  int plain_div; /* bit 0: speed, bit 1: cell_mfp inside the plain division range */
   unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
   unsigned nevents; /* events of this history so far: watchdog only */
@@ -171,6 +175,16 @@ __device__ __forceinline__ double half_or_quotient(double x, double sum) {
   }
   asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
   return x / sum;
+}
+
+__device__ __forceinline__ void refresh_speed_reciprocal(History& h) {
+  h.r_speed = refined_reciprocal(h.speed);
+  h.plain_div = (h.plain_div & ~1) | (in_plain_division_range(h.speed) ? 1 : 0);
+}
+
+__device__ __forceinline__ void refresh_mfp_reciprocal(History& h) {
+  h.r_cell_mfp = refined_reciprocal(h.cell_mfp);
+  h.plain_div = (h.plain_div & ~2) | (in_plain_division_range(h.cell_mfp) ? 2 : 0);
 }
 
 /* omp3/neutral.c:435-436 */
@@ -434,7 +448,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
  * profiles/r02/ablate_facetloads.log).  Every value is computed from the same
  * operands as in the reference's order: the position update uses the direction
  * BEFORE a reflection, as :329-330 precede :333. */
-template <typename Tally>
+template <bool kCachedReciprocals = false, typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
   /* step to the neighbour cell, or reflect at the outer boundary */
   int ncellx = h.cellx;
@@ -476,8 +490,20 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 #endif
 
   const double distance_to_facet = h.distance;
-  h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
-  h.dt_to_census -= (distance_to_facet / h.speed);
+  if (kCachedReciprocals) {
+    /* both quotients of :311-312 through the kept reciprocals */
+    if (__builtin_expect(h.plain_div == 3 && in_plain_division_range(distance_to_facet), 1)) {
+      h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
+      h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
+    } else {
+      asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+      h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
+      h.dt_to_census -= (distance_to_facet / h.speed);
+    }
+  } else {
+    h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
+    h.dt_to_census -= (distance_to_facet / h.speed);
+  }
   h.energy_deposition += deposit(h, distance_to_facet);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   h.energy_deposition = 0.0;
@@ -506,6 +532,9 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
     macroscopic_from_density(h);
+    if (kCachedReciprocals) {
+      refresh_mfp_reciprocal(h);
+    }
   }
 }
 

@@ -201,6 +201,8 @@ hipError_t launch_probe_cs(const double* keys, const double* values, int nentrie
                            const CsIndex& ix, hipStream_t stream);
 hipError_t launch_probe_facet(const double* in, double* dist, int* x_facet, int n,
                               hipStream_t stream);
+hipError_t launch_probe_division(const double* in, double* out, int* plain, int n,
+                                 hipStream_t stream);
 
 }  // namespace neutral
 #endif

@@ -564,6 +564,26 @@ __global__ __launch_bounds__(kBlock) void probe_facet_kernel(const double* in, d
   }
 }
 
+__global__ __launch_bounds__(kBlock) void probe_division_kernel(const double* in, double* out,
+                                                                 int* plain, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    /* in: {a, b} per row; out: {a / b, quotient through the kept reciprocal} */
+    const double a = in[2 * i];
+    const double b = in[2 * i + 1];
+    out[2 * i] = a / b;
+    out[2 * i + 1] = quotient_by_reciprocal(a, b, refined_reciprocal(b));
+    plain[i] = (in_plain_division_range(a) && in_plain_division_range(b)) ? 1 : 0;
+  }
+}
+
+hipError_t launch_probe_division(const double* in, double* out, int* plain, int n,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(probe_division_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                     stream, in, out, plain, n);
+  return hipGetLastError();
+}
+
 /* ---- launchers -------------------------------------------------------------- */
 
 hipError_t launch_probe_threefry(const uint64_t* in, uint64_t* out, double* rn, int n,

@@ -396,6 +396,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             } else {
               resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
             }
+            h.plain_div = 0;
+            refresh_speed_reciprocal(h); /* no collision here: the speed stays */
+            refresh_mfp_reciprocal(h);
             decide(h, a);
             has = true;
             if (h.ev == kEvCollision) {
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               break;
             }
             nfacets++;
-            cross_facet(h, a, tally);
+            cross_facet<true>(h, a, tally);
             decide(h, a);
             if (h.ev != kEvFacet) {
               if (h.ev == kEvCollision) {

@@ -82,7 +82,7 @@ ABI_SYMBOLS = (
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
-    "neutral_hip_probe_distance_to_facet",
+    "neutral_hip_probe_distance_to_facet", "neutral_hip_probe_division",
 )
 
 _lib = C.CDLL(LIB_PATH)
@@ -126,6 +126,7 @@ _lib.neutral_hip_abi_version.restype = C.c_int
 _lib.neutral_hip_probe_threefry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_cs_lookup.argtypes = [C.POINTER(CrossSection), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+_lib.neutral_hip_probe_division.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_distance_to_facet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int]
 
@@ -237,6 +238,16 @@ def probe_cs_lookup(cs: CrossSection, energies: np.ndarray, use_index: bool = Tr
     _lib.neutral_hip_probe_cs_lookup(C.byref(cs), e.ctypes.data, value.ctypes.data,
                                      index.ctypes.data, e.size, 1 if use_index else 0)
     return value, index
+
+
+def probe_division(rows: np.ndarray):
+    """rows {a, b} -> (a / b, quotient through the kept reciprocal, in-range flag)"""
+    a = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((a.shape[0], 2), dtype=np.float64)
+    plain = np.zeros(a.shape[0], dtype=np.int32)
+    _lib.neutral_hip_probe_division(a.ctypes.data, out.ctypes.data, plain.ctypes.data,
+                                    a.shape[0])
+    return out[:, 0], out[:, 1], plain.astype(bool)
 
 
 def probe_distance_to_facet(rows: np.ndarray):

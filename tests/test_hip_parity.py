@@ -150,6 +150,33 @@ def test_distance_to_facet_matches_oracle(iface):
 
 # ---- injection -------------------------------------------------------------------
 
+def test_quotient_through_kept_reciprocal_is_the_ieee_quotient(iface):
+    """The stream kernel divides a facet's path length by speed and mean free path
+    through reciprocals it keeps across facets (neutral_device.h:
+    quotient_by_reciprocal).  Inside the range where it does so the result must be
+    the bits of the device's own `a / b`, which in turn is the correctly rounded
+    quotient numpy computes."""
+    rng = np.random.default_rng(20260203)
+    n = 2_000_000
+    def doubles(lo_exp, hi_exp, count):
+        mant = rng.random(count) + 1.0                       # [1, 2)
+        # some mantissas with long runs of ones / zeros: the hard cases of division
+        hard = rng.integers(0, 4, count) == 0
+        bits = rng.integers(0, 52, count)
+        mant_hard = 2.0 - np.ldexp(1.0, -bits)
+        mant = np.where(hard, mant_hard, mant)
+        sign = np.where(rng.integers(0, 8, count) == 0, -1.0, 1.0)
+        return sign * np.ldexp(mant, rng.integers(lo_exp, hi_exp, count))
+    a = np.concatenate([doubles(-299, 299, n), doubles(-25, -5, n), doubles(-340, 340, n // 4)])
+    b = np.concatenate([doubles(-299, 299, n), doubles(8, 100, n), doubles(-340, 340, n // 4)])
+    q_dev, q_kept, plain = iface.probe_division(np.stack([a, b], axis=1))
+    with np.errstate(all="ignore"):
+        q_np = a / b
+    assert np.array_equal(q_dev.view(np.uint64), q_np.view(np.uint64))
+    assert plain[: 2 * n].all() and not plain.all()
+    assert np.array_equal(q_kept[plain].view(np.uint64), q_dev[plain].view(np.uint64))
+
+
 @pytest.mark.parametrize("deck", ["scatter", "stream", "csp", "split"])
 def test_inject_matches_oracle(iface, make_problem, cs, deck):
     prob = make_problem(deck, nx=100, nparticles=30000, iterations=1)

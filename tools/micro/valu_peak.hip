@@ -1,0 +1,111 @@
+// Measured VALU issue rates on the box: the denominator for kernels that are bound
+// by fp64 / int64 vector issue rather than by HBM.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/valu_peak.hip -o gpurun_out/valu_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int kIters = 4096;
+
+__global__ __launch_bounds__(256) void fma64_kernel(double* out, double seed) {
+  double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  const double m = 1.0000001, c = 1e-9;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
+      a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// one dependent chain per lane: what a single wave can issue back to back
+__global__ __launch_bounds__(256) void fma64_chain_kernel(double* out, double seed) {
+  double a0 = seed + threadIdx.x;
+  const double m = 1.0000001, c = 1e-9;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) a0 = __builtin_fma(a0, m, c);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0;
+}
+
+__global__ __launch_bounds__(256) void rcp64_kernel(double* out, double seed) {
+  double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 = __builtin_amdgcn_rcp(a0); a1 = __builtin_amdgcn_rcp(a1); a2 = __builtin_amdgcn_rcp(a2); a3 = __builtin_amdgcn_rcp(a3);
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+__global__ __launch_bounds__(256) void add64i_kernel(uint64_t* out, uint64_t seed) {
+  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed | 1;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a0 += b; a1 += a0; a2 += a1; a3 += a2; }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;
+}
+
+__global__ __launch_bounds__(256) void alignbit_kernel(unsigned* out, unsigned seed) {
+  unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a0 = __builtin_amdgcn_alignbit(a0, a1, 7); a1 = __builtin_amdgcn_alignbit(a1, a2, 9);
+      a2 = __builtin_amdgcn_alignbit(a2, a3, 11); a3 = __builtin_amdgcn_alignbit(a3, a0, 13);
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;
+}
+
+template <typename K, typename T>
+static int run(const char* name, K kernel, T* out, T seed, double ops_per_thread, int blocks, const char* unit) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, seed);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < 5; ++r) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, seed);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  const double ops = ops_per_thread * 256.0 * blocks;
+  printf("%-22s %8.3f ms  %10.3f G%s/s  (%d blocks)\n", name, best, ops / (best * 1e-3) / 1e9, unit, blocks);
+  return 0;
+}
+
+int main() {
+  hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
+  const int cus = p.multiProcessorCount;
+  printf("device %s, %d CUs, clock %d MHz\n", p.name, cus, p.clockRate / 1000);
+  void* buf; CHECK(hipMalloc(&buf, 8ull * 256 * cus * 16));
+  for (int per_cu : {4, 8, 12, 16}) {  // 1, 2, 3, 4 waves per SIMD
+    const int blocks = cus * per_cu;
+    printf("-- %d waves/SIMD\n", per_cu / 4);
+    if (run("fma f64 (8 indep.)", fma64_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "FMA")) return 1;
+    if (run("fma f64 (1 chain)", fma64_chain_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "FMA")) return 1;
+    if (run("rcp f64", rcp64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+    if (run("add u64", add64i_kernel, (uint64_t*)buf, (uint64_t)3, kIters * 32.0, blocks, "op")) return 1;
+    if (run("alignbit b32", alignbit_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+  }
+  // peak if every SIMD issued one wave64 instruction per 4 cycles at the reported clock
+  printf("nominal: %d CUs x 4 SIMD x 16 lanes x %.2f GHz = %.1f Glane-op/s\n", cus, p.clockRate / 1e6,
+         cus * 4 * 16 * (p.clockRate / 1e6));
+  return 0;
+}
