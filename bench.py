@@ -101,11 +101,10 @@ def kernel_rooflines(results, same_tables):
              sum(r.stats.sort_ms for r in results) / n, 0.0, 0.0)]
 
 
-def measured_traffic(deck, nx, ntotal, variant, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, made by tools/pmc_traffic.py from separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None when no
-    profile of this exact configuration is committed."""
+def profile_entry(deck, nx, ntotal, variant, kernel):
+    """The committed rocprofv3 PMC figures of `kernel` for this exact configuration
+    (profiles/pmc_traffic.json, made by tools/pmc_traffic.py from separate --pmc
+    passes of this same command), or None when none is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -115,8 +114,47 @@ def measured_traffic(deck, nx, ntotal, variant, kernel):
     for e in table.get("entries", []):
         if (e["deck"], e["nx"], e["nparticles"], e["variant"], e["kernel"]) == \
                 (deck, nx, ntotal, variant, kernel):
-            return e["hbm_bytes_per_launch"]
+            return e
     return None
+
+
+def measured_traffic(deck, nx, ntotal, variant, kernel):
+    """HBM bytes per launch of `kernel` from the FETCH_SIZE / WRITE_SIZE passes."""
+    e = profile_entry(deck, nx, ntotal, variant, kernel)
+    return None if e is None else e["hbm_bytes_per_launch"]
+
+
+# vector issue: one wave64 instruction per SIMD per 4 cycles (16 lanes per cycle),
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz.  tools/micro/valu_peak.hip
+# measures 95.7 % of it with f64 FMAs (profiles/r02/valu_peak.log).
+VALU_PEAK_WAVE_SLOTS = 256 * 4 * 2.4e9 / 4
+
+
+def valu_issue(deck, nx, ntotal, variant, kernel, kernel_ms):
+    """What actually bounds the history kernels: vector
+    instruction issue.  Wave-level VALU instructions per launch from the committed
+    PMC pass; a quarter-rate f64 instruction (rcp/rsq/sqrt) holds the SIMD for four
+    issue slots.  The live launch duration of this run prices them."""
+    e = profile_entry(deck, nx, ntotal, variant, kernel)
+    if e is None or "SQ_INSTS_VALU_per_launch" not in e:
+        return None
+    insts = e["SQ_INSTS_VALU_per_launch"]
+    trans = e.get("SQ_INSTS_VALU_TRANS_F64_per_launch", 0.0)
+    slots = insts + 3.0 * trans
+    achieved = slots / (kernel_ms * 1e-3)
+    out = {"kernel": kernel, "wave_valu_insts_per_launch": insts,
+           "quarter_rate_f64_insts_per_launch": trans, "issue_slots_per_launch": slots,
+           "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_SLOTS / 1e9,
+           "unit": "G wave-instruction slots/s", "frac": achieved / VALU_PEAK_WAVE_SLOTS,
+           "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
+    if e.get("SQ_ACTIVE_INST_VALU_per_launch"):
+        out["lane_utilisation"] = e.get("SQ_THREAD_CYCLES_VALU_per_launch", 0.0) / \
+            (e["SQ_ACTIVE_INST_VALU_per_launch"] * 64.0)
+    if e.get("GRBM_GUI_ACTIVE_per_launch"):
+        # summed over the 8 XCDs; busy cycles / wall time = effective shader clock
+        out["effective_clock_ghz_profiled"] = e["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / \
+            (kernel_ms * 1e-3) / 1e9
+    return out
 
 
 def measured_copy_bandwidth(device):
@@ -360,10 +398,14 @@ def main():
                              "own_algorithm": None if dom[3] is None else {
                                  "touched_bytes_per_launch": dom[3],
                                  "achieved": dom[3] / (dom[1] * 1e-3) / 1e9,
-                                 "frac": dom[3] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                                 "frac": dom[3] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                             "valu_issue": valu_issue(deck, nx, ntotal, int(stats.variant),
+                                                      dom[0], dom[1])},
                 "kernels": [{"name": k[0], "ms_per_launch": k[1],
                              "algorithmic_bytes_per_launch": k[2],
-                             "touched_bytes_per_launch": k[3]} for k in kernels],
+                             "touched_bytes_per_launch": k[3],
+                             "valu_issue": valu_issue(deck, nx, ntotal, int(stats.variant),
+                                                      k[0], k[1])} for k in kernels],
             }
             out["roofline"]["hbm_copy_measured_gbs"] = measured_copy_bandwidth(sim.device)
             if world == 1 and not args.no_cpu_baseline:

@@ -116,7 +116,7 @@ struct SolveArgs {
   StepCounters* counters;
   /* optional work list for the regroup kernel: ids of particles another kernel
    * suspended at their first collision (null: all particles 0..nparticles-1) */
-  const unsigned* queue;
+  unsigned* queue;           /* (the collision stage re-uses its words as per-wave rings) */
   const unsigned* queue_len; /* [device] number of valid entries */
   ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
   int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU */

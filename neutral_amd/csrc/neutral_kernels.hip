@@ -189,30 +189,49 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
  * many waves share its SIMD), and chains of one deck are about equally long.
  * Handing ids out first-come-first-served therefore runs in GENERATIONS: with
  * 1.5 histories per lane the second generation occupies every wave at half its
- * lanes for another full chain (9.8 ms where the work is worth 7.3).  So when
- * the queue is short enough for it, every wave takes an equal, strided share of
- * the queue into a ring in LDS and ROUND-ROBINS its lanes over the share: every
- * kSlicePasses collision passes the colliding lanes put their histories at the
- * back of the ring (record + SuspendExtra) and take the ones at the front, as
- * long as any are waiting.  All histories of a wave then finish within one
- * slice of each other, every lane stays busy until then, and no wave depends on
- * another (no in-launch hand-off between waves, nothing to wait for).
+ * lanes for another full chain (9.8 ms where the work is worth 7.3), and with
+ * many generations the last one still ends ragged.  So every wave takes an
+ * equal, STRIDED share of the queue (wave w: entries w, w + #waves, ...; strided
+ * because the queue is in tile order and chain length follows position) and
+ * ROUND-ROBINS its lanes over the share: every kSlicePasses collision passes
+ * the colliding lanes put their histories at the back of the wave's ring
+ * (record + SuspendExtra) and take the ones at the front, as long as any are
+ * waiting.  All histories of a wave then finish within one slice of each other,
+ * every lane stays busy until then, and no wave depends on another (no
+ * in-launch hand-off between waves, nothing to wait for).
+ * The ring is the wave's own slots of the queue array: at most `share`
+ * histories are ever outstanding, so position i of the ring is queue entry
+ * w + (i mod share) * #waves; only this wave reads or writes those words.
  * A swap costs a record store/load and resume() -- about a fifth of a collision
  * every kSlicePasses collisions.  Histories execute exactly the events they
  * would execute unsliced: the record, the RNG counter and the pending
  * deposition are all that survives a loop head (see resume()). */
-constexpr int kPoolCap = 1024; /* ring entries per wave (power of two) */
 #ifndef NEUTRAL_SLICE_PASSES
 #define NEUTRAL_SLICE_PASSES 64
 #endif
 constexpr int kSlicePasses = NEUTRAL_SLICE_PASSES;
+/* Measured (profiles/r02/ablate_shares.log, ablate_slicewindow.log):
+ *  - slicing THROUGHOUT a share beats slicing only near its end by 9-17 %: lanes
+ *    that swap together stay at the same collision count, hence at similar
+ *    energies, and their cs-table probes fall into few cache lines; lanes refilled
+ *    one by one drift apart and every probe becomes 64 separate L1 requests.
+ *    NEUTRAL_SLICE_WINDOW > 0 restricts slicing to the last so-many waiting
+ *    histories (experiment knob; 0 = throughout).
+ *  - strided or contiguous shares make no difference.
+ *  - with tens of generations per wave (scatter, split at 1e8: 30 000 histories per
+ *    wave) the first-come-first-served queue of variant 1 is 3-6 % faster than
+ *    slicing (no record round trips, and its ragged end is under 1 % of the
+ *    run), so shares above kPoolMaxShare keep it. */
+#ifndef NEUTRAL_SLICE_WINDOW
+#define NEUTRAL_SLICE_WINDOW 0
+#endif
+constexpr int kSliceWindow = NEUTRAL_SLICE_WINDOW;
+#ifndef NEUTRAL_POOL_MAX_SHARE
+#define NEUTRAL_POOL_MAX_SHARE 2048
+#endif
+constexpr int kPoolMaxShare = NEUTRAL_POOL_MAX_SHARE;
 constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is valid */
 
-__device__ __forceinline__ void wave_lds_sync() {
-  /* LDS operations of one wave execute in order; this only pins the compiler */
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 /* final state of a history: into the SoA store, or into its record in queue mode */
 template <bool kQueue>
@@ -258,15 +277,6 @@ void history_regroup_kernel(SolveArgs a) {
     }
     __syncthreads();
   }
-  /* this wave's ring, behind the index(es); queue mode only */
-  unsigned* ring = nullptr;
-  if (kQueue) {
-    int idx_entries = a.scatter_index ? a.scatter_index_n + 1 : 0;
-    if (!kSameTables && a.absorb_index) {
-      idx_entries += a.absorb_index_n + 1;
-    }
-    ring = (unsigned*)(lds_index + ((idx_entries + 7) & ~7)) + (threadIdx.x >> 6) * kPoolCap;
-  }
 
   const GlobalTally tally;
   /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
@@ -303,21 +313,32 @@ void history_regroup_kernel(SolveArgs a) {
   int end = 0;
   bool drained = false;
 
-  /* pooled mode: the wave's strided share of the queue goes into its ring */
-  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolCap);
-  unsigned ring_head = 0; /* wave-uniform, free-running; entry i lives at i & (kPoolCap-1) */
-  unsigned ring_tail = 0;
+  /* pooled mode (the collision stage): the wave's strided share of the queue is its
+   * ring; all wave-uniform */
+  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare);
+  const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
+#if defined(NEUTRAL_EXP_CONTIGUOUS_SHARES)
+  /* experiment: wave w owns the contiguous block [w * per, (w + 1) * per) */
+  const int per = (nwork + nwaves - 1) / nwaves;
+  const int first = gw * per;
+  const int share = (pooled && first < nwork) ? ((first + per <= nwork) ? per : nwork - first) : 0;
+#else
+  const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
+#endif
+  int ring_head = 0;      /* ring position of the oldest waiting history, in [0, share) */
+  int ring_count = share; /* histories waiting in the ring */
   int slice = 0;
   unsigned w_requeued = 0;
+  /* ring position -> queue entry (pos < 2 * share) */
+  auto ring_slot = [&](int pos) -> unsigned* {
+#if defined(NEUTRAL_EXP_CONTIGUOUS_SHARES)
+    return a.queue + ((size_t)first + (size_t)((pos >= share) ? pos - share : pos));
+#else
+    return a.queue + ((size_t)gw + (size_t)((pos >= share) ? pos - share : pos) * (size_t)nwaves);
+#endif
+  };
   if (pooled) {
-    const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
-    const int share = (gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
-    for (int k = (int)(threadIdx.x & 63); k < share; k += 64) {
-      ring[k] = a.queue[gw + k * nwaves];
-    }
-    ring_tail = (unsigned)share;
     drained = (share == 0);
-    wave_lds_sync();
   }
 
   for (;;) {
@@ -350,11 +371,10 @@ void history_regroup_kernel(SolveArgs a) {
 
     if (pass == kWantRefill && pooled) {
       /* ---- REFILL pass, pooled: the histories at the front of the ring ---- */
-      const int avail = (int)(ring_tail - ring_head);
-      const int n_take = (n_refill < avail) ? n_refill : avail;
+      const int n_take = (n_refill < ring_count) ? n_refill : ring_count;
       const int rank = lane_rank(m_refill);
       if (want == kWantRefill && rank < n_take) {
-        const unsigned e = ring[(ring_head + (unsigned)rank) & (kPoolCap - 1)];
+        const unsigned e = *ring_slot(ring_head + rank);
         pid = (int)(e & ~kRequeued);
         load_record(h, a, a.rec[pid]);
         resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
@@ -367,8 +387,10 @@ void history_regroup_kernel(SolveArgs a) {
         next_event(true);
         want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
       }
-      ring_head += (unsigned)n_take;
-      drained = (ring_head == ring_tail);
+      ring_head += n_take;
+      ring_head = (ring_head >= share) ? ring_head - share : ring_head;
+      ring_count -= n_take;
+      drained = (ring_count == 0);
     } else if (pass == kWantRefill) {
       /* ---- REFILL pass: hand fresh particle ids to the empty lanes ---- */
       if (cur >= end) {
@@ -423,7 +445,8 @@ void history_regroup_kernel(SolveArgs a) {
           want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
         }
       }
-      if (pooled && ++slice >= kSlicePasses && ring_head != ring_tail) {
+      if (pooled && ++slice >= kSlicePasses && ring_count > 0 &&
+          (kSliceWindow == 0 || ring_count <= kSliceWindow)) {
         /* ---- end of a time slice: colliders swap with the waiting histories ---- */
         slice = 0;
         const bool out = (want == kWantCollide);
@@ -435,16 +458,19 @@ void history_regroup_kernel(SolveArgs a) {
           x.counter = h.counter;
           x.nevents = h.nevents;
           a.susp[pid] = x;
-          ring[(ring_tail + (unsigned)lane_rank(m_out)) & (kPoolCap - 1)] = (unsigned)pid | kRequeued;
+          /* outstanding histories never exceed the share: the slot is free */
+          int back = ring_head + ring_count;
+          back = (back >= share) ? back - share : back;
+          *ring_slot(back + lane_rank(m_out)) = (unsigned)pid | kRequeued;
           want = kWantRefill;
         }
-        ring_tail += (unsigned)__popcll(m_out);
+        ring_count += __popcll(m_out);
         w_requeued += (unsigned)__popcll(m_out);
         drained = false;
-        /* the same wave reads these records back later, possibly from another
-         * lane: stores complete (workgroup scope: same CU, same L1) first */
+        /* the same wave reads these records and ring words back later, possibly
+         * from another lane: stores complete (workgroup scope: same CU, same L1)
+         * first */
         __threadfence_block();
-        wave_lds_sync();
       }
     } else {
       /* ---- STREAM pass: facet crossings, census, end of history ---- */
@@ -657,12 +683,7 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     if (!a.same_tables && a.absorb_index) {
       idx_entries += (size_t)(a.absorb_index_n + 1);
     }
-    size_t lds = sizeof(unsigned short) * idx_entries;
-    if (a.queue) {
-      /* one ring per wave behind the index(es), see history_regroup_kernel */
-      lds = sizeof(unsigned short) * ((idx_entries + 7) & ~(size_t)7) +
-            sizeof(unsigned) * (size_t)kPoolCap * (kBlock / 64);
-    }
+    const size_t lds = sizeof(unsigned short) * idx_entries;
     auto launch = [&](auto kernel) {
       int grid = resident_blocks(kernel);
       if (a.blocks_per_cu > 0) {

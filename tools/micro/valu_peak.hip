@@ -47,14 +47,75 @@ __global__ __launch_bounds__(256) void rcp64_kernel(double* out, double seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
 }
 
+// 64-bit integer add as the compiler emits it for Threefry (v_lshl_add_u64); the xor
+// between the adds keeps the chain from folding into a closed form
 __global__ __launch_bounds__(256) void add64i_kernel(uint64_t* out, uint64_t seed) {
-  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed | 1;
+  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
 #pragma unroll 1
   for (int i = 0; i < kIters; ++i) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a0 += b; a1 += a0; a2 += a1; a3 += a2; }
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a0) : "v"(a1));
+      asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a1) : "v"(a2));
+      asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a2) : "v"(a3));
+      asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a3) : "v"(a0));
+    }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;
+}
+
+#define ASM4(INSN)                                             \
+  asm volatile(INSN : "+v"(a0) : "v"(a1), "v"(a2));            \
+  asm volatile(INSN : "+v"(a1) : "v"(a2), "v"(a3));            \
+  asm volatile(INSN : "+v"(a2) : "v"(a3), "v"(a0));            \
+  asm volatile(INSN : "+v"(a3) : "v"(a0), "v"(a1));
+
+#define F64_KERNEL(NAME, INSN)                                                   \
+  __global__ __launch_bounds__(256) void NAME(double* out, double seed) {        \
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;       \
+    _Pragma("unroll 1") for (int i = 0; i < kIters; ++i) {                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { ASM4(INSN) }               \
+    }                                                                            \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;              \
+  }
+
+F64_KERNEL(mul64_kernel, "v_mul_f64 %0, %0, %1")
+F64_KERNEL(add64f_kernel, "v_add_f64 %0, %0, %1")
+F64_KERNEL(divfixup_kernel, "v_div_fixup_f64 %0, %0, %1, %2")
+F64_KERNEL(divfmas_kernel, "v_div_fmas_f64 %0, %0, %1, %2")
+F64_KERNEL(ldexp_kernel, "v_ldexp_f64 %0, %0, 1")
+F64_KERNEL(rsq64_kernel, "v_rsq_f64 %0, %0")
+F64_KERNEL(sqrt64_kernel, "v_sqrt_f64 %0, %0")
+
+__global__ __launch_bounds__(256) void divscale_kernel(double* out, double seed) {
+  double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(a0) : "v"(a1) : "vcc");
+      asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(a1) : "v"(a2) : "vcc");
+      asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(a2) : "v"(a3) : "vcc");
+      asm volatile("v_div_scale_f64 %0, vcc, %0, %1, %0" : "+v"(a3) : "v"(a0) : "vcc");
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+__global__ __launch_bounds__(256) void cvt_u32_f64_kernel(double* out, double seed) {
+  double a0 = seed, a1 = seed, a2 = seed, a3 = seed;
+  unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a0) : "v"(u0));
+      asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a1) : "v"(u1));
+      asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a2) : "v"(u2));
+      asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a3) : "v"(u3));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
 }
 
 __global__ __launch_bounds__(256) void alignbit_kernel(unsigned* out, unsigned seed) {
@@ -103,6 +164,17 @@ int main() {
     if (run("rcp f64", rcp64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
     if (run("add u64", add64i_kernel, (uint64_t*)buf, (uint64_t)3, kIters * 32.0, blocks, "op")) return 1;
     if (run("alignbit b32", alignbit_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (per_cu == 16) {
+      if (run("v_mul_f64", mul64_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_add_f64", add64f_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_div_scale_f64", divscale_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_div_fmas_f64", divfmas_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_div_fixup_f64", divfixup_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_ldexp_f64", ldexp_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_rsq_f64", rsq64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_sqrt_f64", sqrt64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_cvt_f64_u32", cvt_u32_f64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
+    }
   }
   // peak if every SIMD issued one wave64 instruction per 4 cycles at the reported clock
   printf("nominal: %d CUs x 4 SIMD x 16 lanes x %.2f GHz = %.1f Glane-op/s\n", cus, p.clockRate / 1e6,
