@@ -126,7 +126,7 @@ def measured_traffic(deck, nx, ntotal, variant, kernel):
 
 # vector issue: one wave64 instruction per SIMD per 4 cycles (16 lanes per cycle),
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz.  tools/micro/valu_peak.hip
-# measures 95.7 % of it with f64 FMAs (profiles/r02/valu_peak.log).
+# measures 95.7 % of it with f64 FMAs (profiles/r01g/valu_peak.log).
 VALU_PEAK_WAVE_SLOTS = 256 * 4 * 2.4e9 / 4
 
 

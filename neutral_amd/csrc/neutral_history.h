@@ -445,7 +445,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
  * before the floating-point updates (:311-330) so that the density load of the
  * new cell (:372) is in flight while they execute -- issued after them it is a
  * dependent L2 round trip per facet (14 % of the stream kernel,
- * profiles/r02/ablate_facetloads.log).  Every value is computed from the same
+ * profiles/r01g/ablate_facetloads.log).  Every value is computed from the same
  * operands as in the reference's order: the position update uses the direction
  * BEFORE a reflection, as :329-330 precede :333. */
 template <bool kCachedReciprocals = false, typename Tally>

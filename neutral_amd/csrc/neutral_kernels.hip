@@ -210,7 +210,7 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
 #define NEUTRAL_SLICE_PASSES 64
 #endif
 constexpr int kSlicePasses = NEUTRAL_SLICE_PASSES;
-/* Measured (profiles/r02/ablate_shares.log, ablate_slicewindow.log):
+/* Measured (profiles/r01g/ablate_shares.log, ablate_slicewindow.log):
  *  - slicing THROUGHOUT a share beats slicing only near its end by 9-17 %: lanes
  *    that swap together stay at the same collision count, hence at similar
  *    energies, and their cs-table probes fall into few cache lines; lanes refilled
