@@ -170,6 +170,9 @@ typedef struct {
   uint64_t requeued;    /* tiled variant: times the collision stage put a history back in
                            its wave's ring at the end of a time slice (0 when every
                            wave's share of the collision queue fitted its lanes) */
+  uint64_t collide_passes; /* wave-level collision passes of the event-regrouped kernel
+                           (variants 1, 2): collisions / (64 * collide_passes) is the
+                           lane occupancy of its collision passes */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

@@ -500,6 +500,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
   g.last.stream_passes = tiled ? g.last_passes : 0;
   g.last.requeued = tiled ? hc[1].nrequeued : 0;
+  g.last.collide_passes = hc[0].ncollide_passes + hc[1].ncollide_passes;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

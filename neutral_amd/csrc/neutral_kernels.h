@@ -78,6 +78,7 @@ struct StepCounters {
   unsigned int queue_head;    /* K2: next unclaimed particle index */
   unsigned int aborted;       /* histories stopped by the event watchdog (should be 0) */
   unsigned long long nrequeued; /* time-slice swaps of the collision stage (queue mode) */
+  unsigned long long ncollide_passes; /* wave-level COLLIDE passes of the regroup kernel */
 };
 
 struct SolveArgs {

@@ -329,6 +329,7 @@ void history_regroup_kernel(SolveArgs a) {
   int ring_count = share; /* histories waiting in the ring */
   int slice = 0;
   unsigned w_requeued = 0;
+  unsigned w_collide_passes = 0;
   /* ring position -> queue entry (pos < 2 * share) */
   auto ring_slot = [&](int pos) -> unsigned* {
 #if defined(NEUTRAL_EXP_CONTIGUOUS_SHARES)
@@ -435,6 +436,7 @@ void history_regroup_kernel(SolveArgs a) {
       }
     } else if (pass == kWantCollide) {
       /* ---- COLLIDE pass ---- */
+      w_collide_passes++;
       if (want == kWantCollide) {
         ncollisions++;
         if (collide<kSameTables>(h, a, ix, tally)) {
@@ -492,8 +494,11 @@ void history_regroup_kernel(SolveArgs a) {
     }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
-  if (w_requeued && (threadIdx.x & 63) == 0) {
-    atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
+  if ((threadIdx.x & 63) == 0) {
+    if (w_requeued) atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
+    if (w_collide_passes) {
+      atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
+    }
   }
 }
 

@@ -64,7 +64,7 @@ class StepStats(C.Structure):
                 ("collide_ms", C.c_double), ("stream_facets", C.c_uint64),
                 ("stream_census", C.c_uint64), ("suspended", C.c_uint64),
                 ("aborted", C.c_uint64), ("stream_passes", C.c_int),
-                ("requeued", C.c_uint64)]
+                ("requeued", C.c_uint64), ("collide_passes", C.c_uint64)]
 
 
 # every symbol include/neutral_hip.h declares

@@ -14,4 +14,4 @@ with tempfile.TemporaryDirectory() as tmp:
         r = sim.step(tt); s = r.stats
         print(f"step {tt}: live {r.nprocessed} suspended {s.suspended} collisions {r.collisions} "
               f"coll/susp {r.collisions/max(1,s.suspended):.0f} stream {s.stream_ms:.2f} ms collide {s.collide_ms:.2f} ms "
-              f"sort {s.sort_ms:.2f} k2facets {r.facets - s.stream_facets} requeued {s.requeued} -> {r.collisions/max(1e-9,s.collide_ms)/1e6:.1f} Gcoll/s")
+              f"sort {s.sort_ms:.2f} k2facets {r.facets - s.stream_facets} requeued {s.requeued} lanes/pass {r.collisions/max(1,s.collide_passes):.1f} -> {r.collisions/max(1e-9,s.collide_ms)/1e6:.1f} Gcoll/s")
