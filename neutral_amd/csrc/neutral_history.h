@@ -450,39 +450,20 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
  * BEFORE a reflection, as :329-330 precede :333. */
 template <bool kCachedReciprocals = false, typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
-  /* step to the neighbour cell, or reflect at the outer boundary */
-  int ncellx = h.cellx;
-  int ncelly = h.celly;
-  bool reflect = false;
-  if (h.x_facet) {
-    if (h.omega_x > 0.0) {
-      if (h.cellx >= (a.global_nx - 1)) {
-        reflect = true;
-      } else {
-        ncellx++;
-      }
-    } else if (h.omega_x < 0.0) {
-      if (h.cellx <= 0) {
-        reflect = true;
-      } else {
-        ncellx--;
-      }
-    }
-  } else {
-    if (h.omega_y > 0.0) {
-      if (h.celly >= (a.global_ny - 1)) {
-        reflect = true;
-      } else {
-        ncelly++;
-      }
-    } else if (h.omega_y < 0.0) {
-      if (h.celly <= 0) {
-        reflect = true;
-      } else {
-        ncelly--;
-      }
-    }
-  }
+  /* step to the neighbour cell, or reflect at the outer boundary (:333-369), as
+   * selects: the branch ladder of the reference costs ~35 scalar instructions of
+   * exec-mask bookkeeping per facet, and the stream kernel issues 0.7 scalar
+   * instructions per vector instruction as it is */
+  const bool xf = (h.x_facet != 0);
+  const double omega = xf ? h.omega_x : h.omega_y;
+  const int cell = xf ? h.cellx : h.celly;
+  const int last = (xf ? a.global_nx : a.global_ny) - 1;
+  const bool forward = (omega > 0.0);
+  const bool backward = (omega < 0.0);
+  const bool reflect = (forward && cell >= last) || (backward && cell <= 0);
+  const int step = reflect ? 0 : (forward ? 1 : (backward ? -1 : 0));
+  const int ncellx = h.cellx + (xf ? step : 0);
+  const int ncelly = h.celly + (xf ? 0 : step);
 #if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
   const double new_density = h.local_density; /* timing experiment only (uniform decks) */
 #else
@@ -511,17 +492,14 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   h.x += distance_to_facet * h.omega_x;
   h.y += distance_to_facet * h.omega_y;
 
-  if (reflect) {
-    /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
-     * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
-    if (h.x_facet) {
-      h.omega_x = -h.omega_x;
-      h.u_x_inv = -h.u_x_inv;
-    } else {
-      h.omega_y = -h.omega_y;
-      h.u_y_inv = -h.u_y_inv;
-    }
-  }
+  /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
+   * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
+  const bool flip_x = reflect && xf;
+  const bool flip_y = reflect && !xf;
+  h.omega_x = flip_x ? -h.omega_x : h.omega_x;
+  h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
+  h.omega_y = flip_y ? -h.omega_y : h.omega_y;
+  h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
   h.cellx = ncellx;
   h.celly = ncelly;
 
