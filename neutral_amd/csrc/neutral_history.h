@@ -460,7 +460,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   const int last = (xf ? a.global_nx : a.global_ny) - 1;
   const bool forward = (omega > 0.0);
   const bool backward = (omega < 0.0);
-  const bool reflect = (forward && cell >= last) || (backward && cell <= 0);
+  /* (& and | on purpose: && / || come out as exec-mask regions) */
+  const bool reflect = (forward & (cell >= last)) | (backward & (cell <= 0));
   const int step = reflect ? 0 : (forward ? 1 : (backward ? -1 : 0));
   const int ncellx = h.cellx + (xf ? step : 0);
   const int ncelly = h.celly + (xf ? 0 : step);
@@ -473,7 +474,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   const double distance_to_facet = h.distance;
   if (kCachedReciprocals) {
     /* both quotients of :311-312 through the kept reciprocals */
-    if (__builtin_expect(h.plain_div == 3 && in_plain_division_range(distance_to_facet), 1)) {
+    if (__builtin_expect((h.plain_div == 3) & in_plain_division_range(distance_to_facet), 1)) {
       h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
       h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
     } else {
@@ -494,8 +495,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 
   /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
    * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
-  const bool flip_x = reflect && xf;
-  const bool flip_y = reflect && !xf;
+  const bool flip_x = reflect & xf;
+  const bool flip_y = reflect & !xf;
   h.omega_x = flip_x ? -h.omega_x : h.omega_x;
   h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
   h.omega_y = flip_y ? -h.omega_y : h.omega_y;
