@@ -363,16 +363,13 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const Cel
                          e.x_lo, e.x_hi, e.y_lo, e.y_hi, distance_to_facet, h.x_facet);
   const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
   const double distance_to_census = h.speed * h.dt_to_census;
-  if (distance_to_collision < distance_to_facet && distance_to_collision < distance_to_census) {
-    h.ev = kEvCollision;
-    h.distance = distance_to_collision;
-  } else if (distance_to_facet < distance_to_census) {
-    h.ev = kEvFacet;
-    h.distance = distance_to_facet;
-  } else {
-    h.ev = kEvCensus;
-    h.distance = distance_to_census;
-  }
+  /* omp3/neutral.c:150,170 as selects (& on purpose: no exec-mask regions) */
+  const bool collides = (distance_to_collision < distance_to_facet) &
+                        (distance_to_collision < distance_to_census);
+  const bool crosses = (distance_to_facet < distance_to_census);
+  h.ev = collides ? kEvCollision : (crosses ? kEvFacet : kEvCensus);
+  h.distance = collides ? distance_to_collision
+                        : (crosses ? distance_to_facet : distance_to_census);
 }
 
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
