@@ -22,7 +22,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 1
+#define NEUTRAL_ABI_VERSION 2 /* 2: probe_division, NeutralHipStepStats grew requeued + collide_passes */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
 #define NEUTRAL_VALIDATE_TOLERANCE 1.0e-3 /* neutral_data.h:27 */
