@@ -174,7 +174,7 @@ constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is pl
 #define NEUTRAL_QUEUE_CHUNK_MIN 8
 #endif
 #ifndef NEUTRAL_REFILL_MIN
-#define NEUTRAL_REFILL_MIN 8
+#define NEUTRAL_REFILL_MIN 4
 #endif
 #ifndef NEUTRAL_COLLIDE_MIN
 #define NEUTRAL_COLLIDE_MIN 48
@@ -358,7 +358,14 @@ void history_regroup_kernel(SolveArgs a) {
      * passes run as long as any lane wants one; REFILL runs once enough lanes
      * are empty to amortise the prologue, or when nothing else can run. */
     int pass;
-    if (n_collide >= kCollideMin) {
+    /* With the first-come queue an empty lane costs a 64th of every collision pass
+     * until it is refilled, and colliders only drop below kCollideMin once 17 lanes
+     * are empty: refilling as soon as kRefillMin are is worth 7-10 % on scatter and
+     * split (profiles/r01g/ablate_refillfirst*.log).  A pooled wave's histories end
+     * together, so there the order does not matter and collisions keep priority. */
+    if (!pooled && n_refill >= kRefillMin) {
+      pass = kWantRefill;
+    } else if (n_collide >= kCollideMin) {
       pass = kWantCollide;
     } else if (n_refill >= kRefillMin) {
       pass = kWantRefill;
