@@ -220,37 +220,78 @@ __global__ __launch_bounds__(kSortBlock) void tile_bounds_kernel(SolveArgs a, Ti
   }
 }
 
-/* single workgroup: the chunk list, from the tile populations */
+/* single workgroup: the chunk list, from the tile populations.
+ *
+ * A tile with at least kWindowMinParticles particles is cut into chunks of its own
+ * (they stream with the LDS window centred on the tile).  Tiles below that are not
+ * worth a window, so they need no chunk of their own either: consecutive sparse
+ * tiles -- contiguous in the sorted order -- are MERGED into un-windowed chunks of
+ * up to chunk_particles.  Without that a sparse problem (the reference's shipped
+ * decks: 4000^2 cells, 1e6 particles, 16 per tile) hands 1024-thread workgroups
+ * sixteen particles at a time (csp default deck: 822 -> see DESIGN.md).
+ * Every thread owns a contiguous range of tiles sized to hold about one chunk of
+ * particles; a run of sparse tiles ends at the range's end. */
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   __shared__ unsigned s_chunks[1024];
   const int tid = threadIdx.x;
-  const int per = (t.ntiles + 1023) / 1024;
-  const int lo = tid * per;
-  const int hi = (lo + per < t.ntiles) ? lo + per : t.ntiles;
+  const unsigned nactive = t.tile_offset[t.ntiles];
+  long long per = (t.ntiles + 1023) / 1024;
+  if (nactive > 0) {
+    const long long per_sparse =
+        ((long long)t.chunk_particles * (long long)t.ntiles + nactive - 1) / (long long)nactive;
+    per = (per_sparse > per) ? per_sparse : per;
+  }
+  per = (per > t.ntiles) ? t.ntiles : per;
+  const long long lo_ll = (long long)tid * per;
+  const int lo = (lo_ll < t.ntiles) ? (int)lo_ll : t.ntiles;
+  const int hi = (lo_ll + per < t.ntiles) ? (int)(lo_ll + per) : t.ntiles;
+  const unsigned cp = (unsigned)t.chunk_particles;
 
+  /* sweep 1 counts this range's chunks, sweep 2 (after the scan) writes them */
   unsigned nch = 0;
-  for (int i = lo; i < hi; ++i) {
-    const unsigned c = t.tile_offset[i + 1] - t.tile_offset[i];
-    nch += (c + t.chunk_particles - 1) / t.chunk_particles;
-  }
-  s_chunks[tid] = nch;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
-    const unsigned c0 = (tid >= off) ? s_chunks[tid - off] : 0;
-    __syncthreads();
-    s_chunks[tid] += c0;
-    __syncthreads();
-  }
-  unsigned chunk = s_chunks[tid] - nch; /* exclusive */
-  for (int i = lo; i < hi; ++i) {
-    const unsigned begin = t.tile_offset[i];
-    const unsigned end = t.tile_offset[i + 1];
-    for (unsigned b = begin; b < end; b += (unsigned)t.chunk_particles) {
-      const unsigned e = (b + t.chunk_particles < end) ? b + t.chunk_particles : end;
-      if (chunk < (unsigned)t.max_chunks) {
-        t.chunks[chunk] = make_uint4(b, e, (unsigned)i, 0u);
+  unsigned chunk = 0;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    unsigned run_begin = 0, run_end = 0; /* pending run of sparse tiles: [begin, end) */
+    auto emit = [&](unsigned begin, unsigned end, unsigned tile, unsigned windowed) {
+      for (unsigned b = begin; b < end; b += cp) {
+        const unsigned e = (b + cp < end) ? b + cp : end;
+        if (sweep == 0) {
+          nch++;
+        } else {
+          if (chunk < (unsigned)t.max_chunks) {
+            /* the last chunk of a dense tile may be too small for a window */
+            t.chunks[chunk] = make_uint4(b, e, tile,
+                                         (windowed && (e - b) >= (unsigned)kWindowMinParticles) ? 1u : 0u);
+          }
+          chunk++;
+        }
       }
-      chunk++;
+    };
+    for (int i = lo; i < hi; ++i) {
+      const unsigned begin = t.tile_offset[i];
+      const unsigned end = t.tile_offset[i + 1];
+      if (end - begin >= (unsigned)kWindowMinParticles) {
+        emit(run_begin, run_end, 0u, 0u);
+        run_begin = run_end = end;
+        emit(begin, end, (unsigned)i, 1u);
+      } else {
+        if (run_end == run_begin) {
+          run_begin = begin;
+        }
+        run_end = end;
+      }
+    }
+    emit(run_begin, run_end, 0u, 0u);
+    if (sweep == 0) {
+      s_chunks[tid] = nch;
+      __syncthreads();
+      for (int off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
+        const unsigned c0 = (tid >= off) ? s_chunks[tid - off] : 0;
+        __syncthreads();
+        s_chunks[tid] += c0;
+        __syncthreads();
+      }
+      chunk = s_chunks[tid] - nch; /* exclusive */
     }
   }
   if (tid == 1023) {
@@ -285,9 +326,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   double* window = lds_raw;                                             /* kWindow^2 f64 */
   unsigned short* lds_index = (unsigned short*)(lds_raw + kWindow * kWindow);
   __shared__ int s_chunk;
-  __shared__ int s_begin;
   __shared__ int s_end;
   __shared__ int s_tile;
+  __shared__ int s_windowed;
   __shared__ int s_cursor;
 
   /* stage the cs index(es), zero the window */
@@ -335,9 +376,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (c < nchunks) {
         const uint4 ch = t.chunks[c];
         s_cursor = (int)ch.x;
-        s_begin = (int)ch.x;
         s_end = (int)ch.y;
         s_tile = (int)ch.z;
+        s_windowed = (int)ch.w;
       }
     }
     __syncthreads();
@@ -345,7 +386,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       break;
     }
     const int chunk_end = s_end;
-    const bool windowed = (chunk_end - s_begin) >= kWindowMinParticles;
+    const bool windowed = (s_windowed != 0); /* a dense tile's chunk (tile_chunks_kernel) */
     if (windowed && s_tile != cur_tile) {
       /* move the window: flush what the previous tile accumulated */
       if (cur_tile >= 0) {
