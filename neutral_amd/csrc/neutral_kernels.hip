@@ -35,8 +35,10 @@ constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
  * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  K2
- * needs 141 without spilling; the two instantiations make opposite choices,
- * see history_regroup_kernel (profiles/r01e/baseline_configs.log). */
+ * needs ~147 without spilling; the two instantiations make opposite choices, see
+ * history_regroup_kernel (profiles/r01e/baseline_configs.log).  The collision
+ * stage is bound by vector issue: at 4 waves (56 B of scratch) it runs exactly as
+ * fast as at 3 (profiles/r01g). */
 #ifndef NEUTRAL_K1_WAVES
 #define NEUTRAL_K1_WAVES 3
 #endif
@@ -166,8 +168,10 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
  * A lane runs exactly the event sequence K1 would run for the same particle
  * (same neutral_history.h bodies, same RNG counters), so particle end states
  * are bit-identical to K1; only the order of the tally atomics differs.
- * Exit: the queue head only grows, a wave leaves when the queue is drained and
- * none of its lanes holds a particle -- every wave reaches that state.
+ * Exit: the queue head only grows (first-come queue) or the wave's own ring only
+ * shrinks between the swaps of its own lanes (pooled mode, below); a wave leaves
+ * when nothing is left to claim and none of its lanes holds a particle -- every
+ * wave reaches that state without waiting for any other.
  */
 constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is plentiful */
 #ifndef NEUTRAL_QUEUE_CHUNK_MIN

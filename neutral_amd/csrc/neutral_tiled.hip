@@ -83,9 +83,11 @@ constexpr int kMaxStreamPasses = 64;
 /* a history leaves its window for another pass only if about this many facet
  * crossings still lie ahead; shorter tails finish with global atomics */
 constexpr double kMigrateMinFacets = 8.0;
-/* a chunk smaller than this tallies straight to HBM: flushing a 16 384-cell
- * window costs more than the few atomics it would save, and its particles never
- * migrate (sparse problems degrade to the plain event-regrouped behaviour) */
+/* a tile (or the last chunk of one) with fewer particles than this tallies straight
+ * to HBM: flushing a 16 384-cell window costs more than the few atomics it would
+ * save, and its particles never migrate.  Such tiles share chunks with their
+ * neighbours in the sorted order (tile_chunks_kernel), so sparse problems degrade
+ * to the plain event-regrouped behaviour, not below it */
 constexpr int kWindowMinParticles = 2048;
 
 __device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly) {
