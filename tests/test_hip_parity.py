@@ -499,6 +499,69 @@ def test_collision_stage_time_slicing_is_bitwise_neutral(iface, make_problem, cs
     assert np.linalg.norm(t2 - ref.tally) / np.linalg.norm(ref.tally) < TALLY_L2_TOL
 
 
+def _random_deck_text(rng):
+    """A deck the reference's loader would accept: a source box, a vacuum background
+    and one to three denser boxes, on a mesh that need not be square."""
+    nx, ny = int(rng.integers(20, 260)), int(rng.integers(20, 260))
+    sw, sh = rng.uniform(0.02, 0.5, 2)
+    sx, sy = rng.uniform(0.0, 1.0 - sw), rng.uniform(0.0, 1.0 - sh)
+    lines = [f"source xpos={sx!r} ypos={sy!r} width={sw!r} height={sh!r}",
+             "problem_0 density=1e-30 energy=0.0 xpos=0.0 ypos=0.0 width=1.0 height=1.0"]
+    for i in range(int(rng.integers(1, 4))):
+        bw, bh = rng.uniform(0.05, 0.7, 2)
+        bx, by = rng.uniform(0.0, 1.0 - bw), rng.uniform(0.0, 1.0 - bh)
+        dens = float(10.0 ** rng.uniform(-2, 4))
+        lines.append(f"problem_{i + 1} density={dens!r} energy=1.0 xpos={bx!r} ypos={by!r} "
+                     f"width={bw!r} height={bh!r}")
+    n = int(rng.integers(1, 20000))
+    e0 = float(10.0 ** rng.uniform(2, 6))
+    dt = float(10.0 ** rng.uniform(-8, -6.3))
+    its = int(rng.integers(1, 4))
+    lines += [f"nparticles {n}", f"initial_energy {e0!r}", f"dt {dt!r}", f"nx {nx}", f"ny {ny}",
+              f"iterations {its}", "visit_dump 0"]
+    return "\n".join(lines) + "\n", its
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_decks_match_oracle(iface, cs, tmp_path, monkeypatch, seed):
+    """Differential run on decks nobody tuned for: random source and density boxes,
+    non-square meshes, random particle counts, energies and timesteps, a random kernel
+    variant, and (for the tiled one) a random small grid of the collision kernel so
+    that pooled shares of every size, time slicing included, are exercised.  Event
+    counts and integer state exact, floating-point state and tallies to rounding."""
+    from neutral_amd import decks, host
+    rng = np.random.default_rng(7000 + seed)
+    text, its = _random_deck_text(rng)
+    path = tmp_path / "random.params"
+    path.write_text(text)
+    prob = host.setup_problem(str(path), decks.ARCH_WIDTH, decks.ARCH_HEIGHT)
+    variant = int(rng.integers(0, 3))
+    blocks = [None, 1, 3, 16][int(rng.integers(0, 4))]
+    if blocks is not None:
+        monkeypatch.setenv("NEUTRAL_K2_MAX_BLOCKS", str(blocks))
+    sim = iface.Simulation(prob, *cs, variant=variant)
+    ref = ob.OracleRun(prob, *cs)
+    sim.inject()
+    ref.inject()
+    for tt in range(1, its + 1):
+        g, c = sim.step(tt), ref.step(tt)
+        assert (g.nprocessed, g.facets, g.collisions, g.census) == \
+            (c.nprocessed, c.facets, c.collisions, c.census), text
+        assert iface.last_step().aborted == 0
+    gp, cp = sim.particle_arrays(), ref.particles.as_dict()
+    for f in ("cellx", "celly", "dead"):
+        assert np.array_equal(gp[f], cp[f]), f
+    for f in ("energy", "weight", "dt_to_census", "x", "y"):
+        assert _rel(gp[f], cp[f]) < STATE_TOL, f
+    for f in ("omega_x", "omega_y"):
+        assert np.max(np.abs(gp[f] - cp[f])) < STATE_TOL, f
+    tg, tc = sim.tally_host(), ref.tally
+    if np.linalg.norm(tc) > 0.0:
+        assert np.linalg.norm(tg - tc) / np.linalg.norm(tc) < TALLY_L2_TOL
+    assert np.array_equal(tg == 0.0, tc == 0.0)
+    sim.close()
+
+
 def test_tiled_variant_lazy_export_and_variant_switches(iface, make_problem, cs):
     """The tiled variant's private record store and the SoA arrays stay coherent:
     lazy export + explicit sync, switching variants between steps, reinjection."""
