@@ -137,6 +137,14 @@ template <bool kSameTables, typename IndexPtr>
 __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<IndexPtr>& ix,
                                           double energy, double& micro_scatter,
                                           double& micro_absorb) {
+#if defined(NEUTRAL_EXP_NO_LOOKUP)
+  /* timing experiment only: no table access, a value of the right magnitude */
+  micro_scatter = 900.0 + energy * 1e-9;
+  if (kSameTables) {
+    micro_absorb = micro_scatter;
+    return;
+  }
+#endif
   const int is = bracket_of(a.scatter_keys, a.scatter_n, ix.scatter_index, a.scatter_index_n,
                             a.index_shift, a.scatter_index_base, energy);
   micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
