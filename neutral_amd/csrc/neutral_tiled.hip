@@ -384,24 +384,29 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
     }
     __syncthreads();
-    if (s_chunk >= nchunks) {
+    /* (values read from LDS arrive in vector registers: readfirstlane tells the
+     * compiler they are wave-uniform, so the chunk bookkeeping and the window
+     * origin stay on the scalar unit) */
+    if (__builtin_amdgcn_readfirstlane(s_chunk) >= nchunks) {
       break;
     }
-    const int chunk_end = s_end;
-    const bool windowed = (s_windowed != 0); /* a dense tile's chunk (tile_chunks_kernel) */
-    if (windowed && s_tile != cur_tile) {
+    const int chunk_end = __builtin_amdgcn_readfirstlane(s_end);
+    const int chunk_tile = __builtin_amdgcn_readfirstlane(s_tile);
+    /* a dense tile's chunk (tile_chunks_kernel) */
+    const bool windowed = (__builtin_amdgcn_readfirstlane(s_windowed) != 0);
+    if (windowed && chunk_tile != cur_tile) {
       /* move the window: flush what the previous tile accumulated */
       if (cur_tile >= 0) {
         flush_window(a, window, win_ox, win_oy);
       }
-      cur_tile = s_tile;
+      cur_tile = chunk_tile;
       win_ox = (cur_tile % t.tiles_x) * kTile - kMargin;
       win_oy = (cur_tile / t.tiles_x) * kTile - kMargin;
       __syncthreads();
     }
     /* an un-windowed chunk sees a window that contains no cell */
-    tally.ox = windowed ? win_ox : (1 << 30);
-    tally.oy = windowed ? win_oy : (1 << 30);
+    tally.ox = __builtin_amdgcn_readfirstlane(windowed ? win_ox : (1 << 30));
+    tally.oy = __builtin_amdgcn_readfirstlane(windowed ? win_oy : (1 << 30));
 
     /* ---- this wave's share of the chunk: refill / stream passes ---- */
     bool has = false;      /* lane holds a particle that wants a STREAM pass */
