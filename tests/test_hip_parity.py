@@ -637,6 +637,46 @@ def test_full_size_csp_step_properties(iface, make_problem, cs):
     assert totals[1000000][1] == pytest.approx(totals[100000000][1], rel=2e-3)
 
 
+@pytest.mark.parametrize("deck,nx", [("scatter", 400), ("split", 800)])
+def test_full_size_collision_decks_are_intensive(iface, make_problem, cs, deck, nx):
+    """BASELINE configs 3 and 5 at full size on one GPU (1e8 particles: the collision
+    queue runs 30 000 histories per wave through the first-come path): every source
+    particle is processed exactly once, the tally is non-negative and confined to
+    where particles can be, and events per particle and the (N-normalised) tally
+    equal the 1e6-particle run to Monte-Carlo accuracy.  On scatter every history
+    ends in its first timestep (E0 = 1 keV, ~700 collisions), so a second timestep
+    finds nobody."""
+    per = {}
+    for n in (1000000, 100000000):
+        prob = make_problem(deck, nx=nx, nparticles=n, iterations=2)
+        sim = iface.Simulation(prob, *cs, variant=2)
+        iface.set_lazy_export(True)
+        try:
+            sim.inject()
+            r1 = sim.step(1)
+            assert iface.last_step().aborted == 0
+            r2 = sim.step(2) if deck == "scatter" else None
+        finally:
+            iface.set_lazy_export(False)
+        assert r1.nprocessed == n
+        t = sim.tally_host().reshape(nx, nx)
+        assert np.all(t >= 0.0) and np.isfinite(t).all()
+        if deck == "scatter":
+            assert r2.nprocessed == 0 and r2.collisions == 0
+            assert r1.census == 0
+            # mean free path 1e-5: nothing leaves the source box [0.2, 0.8]^2 by more than a cell
+            lo, hi = int(0.2 * nx) - 2, int(0.8 * nx) + 2
+            assert np.all(t[:lo, :] == 0.0) and np.all(t[hi:, :] == 0.0)
+            assert np.all(t[:, :lo] == 0.0) and np.all(t[:, hi:] == 0.0)
+        per[n] = (r1.collisions / n, r1.facets / n, float(t.sum()))
+        sim.close()
+    small, big = per[1000000], per[100000000]
+    assert small[0] == pytest.approx(big[0], rel=2e-3)
+    assert small[2] == pytest.approx(big[2], rel=5e-3)
+    if deck == "split":
+        assert small[1] == pytest.approx(big[1], rel=5e-3)
+
+
 @pytest.mark.parametrize("deck,nx,its", [("csp", 400, 10), ("split", 800, 1), ("scatter", 400, 1),
                                          ("stream", 400, 1)])
 def test_baseline_shapes_per_cell_tally_l2(iface, make_problem, cs, deck, nx, its):
