@@ -274,7 +274,10 @@ enum RecState : int {
   kRecMigrate = 3,   /* left its tally window, waits for the next streaming pass */
 };
 
-constexpr int kTileCells = 16; /* cells per tile edge of the tiled variant */
+#ifndef NEUTRAL_TILE_CELLS
+#define NEUTRAL_TILE_CELLS 16
+#endif
+constexpr int kTileCells = NEUTRAL_TILE_CELLS; /* cells per tile edge of the tiled variant */
 
 /* record summary: state in the top two bits, tile of the cell below */
 __device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x) {
