@@ -551,7 +551,10 @@ size_t tiled_sort_temp_bytes(int nparticles, int ntiles) {
 
 int tiled_chunk_particles(int nparticles, int compute_units) {
   /* about six chunks per workgroup when every particle is live */
-  long long c = (long long)nparticles / ((long long)compute_units * 6);
+#ifndef NEUTRAL_CHUNKS_PER_WG
+#define NEUTRAL_CHUNKS_PER_WG 6
+#endif
+  long long c = (long long)nparticles / ((long long)compute_units * NEUTRAL_CHUNKS_PER_WG);
   if (c > kChunkParticlesMax) c = kChunkParticlesMax;
   if (c < kChunkParticlesMin) c = kChunkParticlesMin;
   return (int)c;
