@@ -157,6 +157,90 @@ __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<Ind
   }
 }
 
+/* ---- the same lookup in two stages -------------------------------------------
+ * begin: the search window (bucketed index or the whole table) and the first
+ * bisection probe, ISSUED but not waited for; finish: the rest of the bisection
+ * and the interpolation.  Whatever the caller puts between the two runs while the
+ * probe is in flight.  Same comparisons in the same order as cs_bracket(_indexed),
+ * hence the same bracket and the same value. */
+struct BracketSearch {
+  int lo, hi, mid;
+  double kmid;
+};
+
+template <typename IndexPtr>
+__device__ __forceinline__ BracketSearch bracket_begin(const double* __restrict__ keys, int n,
+                                                       IndexPtr index, int index_n, int shift,
+                                                       long long base, double energy) {
+  BracketSearch s;
+  if (index) {
+    long long b = (__double_as_longlong(energy) >> shift) - base;
+    b = (b < 0) ? 0 : ((b > index_n - 1) ? index_n - 1 : b);
+    s.lo = index[b];
+    s.hi = index[b + 1] + 1;
+    s.hi = (s.hi > n - 1) ? n - 1 : s.hi;
+  } else {
+    s.lo = 0;
+    s.hi = n - 1;
+  }
+  s.mid = (s.lo + s.hi) >> 1;
+  s.kmid = keys[s.mid]; /* lo <= mid <= hi: a valid entry even when no probe is needed */
+  return s;
+}
+
+__device__ __forceinline__ int bracket_finish(const double* __restrict__ keys,
+                                              const BracketSearch& s, double energy) {
+  int lo = s.lo;
+  int hi = s.hi;
+  if (hi - lo > 1) {
+    if (energy < s.kmid) {
+      hi = s.mid;
+    } else {
+      lo = s.mid;
+    }
+  }
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (energy < keys[mid]) {
+      hi = mid;
+    } else {
+      lo = mid;
+    }
+  }
+  return lo;
+}
+
+struct CsSearch {
+  BracketSearch scatter, absorb;
+};
+
+template <bool kSameTables, typename IndexPtr>
+__device__ __forceinline__ CsSearch lookup_cs_begin(const SolveArgs& a,
+                                                    const CsLookup<IndexPtr>& ix, double energy) {
+  CsSearch s;
+  s.scatter = bracket_begin(a.scatter_keys, a.scatter_n, ix.scatter_index, a.scatter_index_n,
+                            a.index_shift, a.scatter_index_base, energy);
+  if (!kSameTables) {
+    s.absorb = bracket_begin(a.absorb_keys, a.absorb_n, ix.absorb_index, a.absorb_index_n,
+                             a.index_shift, a.absorb_index_base, energy);
+  }
+  return s;
+}
+
+template <bool kSameTables>
+__device__ __forceinline__ void lookup_cs_finish(const SolveArgs& a, const CsSearch& s,
+                                                 double energy, double& micro_scatter,
+                                                 double& micro_absorb) {
+  const int is = bracket_finish(a.scatter_keys, s.scatter, energy);
+  micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
+  if (kSameTables) {
+    micro_absorb = micro_scatter;
+  } else {
+    const int ia = bracket_finish(a.absorb_keys, s.absorb, energy);
+    micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
+  }
+}
+
 /* macroscopic cross sections from number_density and the microscopic ones
  * (omp3/neutral.c:114-116, :290-291, :376-377) and the loop head's :135 */
 __device__ __forceinline__ void macroscopic_from_micro(History& h) {
@@ -410,7 +494,8 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   double rc0, rc1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
 
-  if (rc0 < p_absorb) {
+  const bool absorbed = (rc0 < p_absorb);
+  if (absorbed) {
     /* absorption: the weight drops; below 1 eV the history ends here */
     h.weight *= (1.0 - p_absorb);
     if (h.energy < kMinEnergyOfInterest) {
@@ -419,11 +504,19 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
       h.energy_deposition = 0.0;
       return true;
     }
-  } else {
+  }
+  /* The energy after the collision is known before the scattering angle is: the
+   * table search for it (:281-286) starts here, and its first probe is in flight
+   * while the scattered lanes work out their direction (:254-272). */
+  double e_new = h.energy;
+  if (!absorbed) {
     /* elastic scatter off a nucleus of mass number A */
     const double mu_cm = 1.0 - 2.0 * rc1;
-    const double e_new = h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0) /
-                         ((kMassNo + 1.0) * (kMassNo + 1.0));
+    e_new = h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0) /
+            ((kMassNo + 1.0) * (kMassNo + 1.0));
+  }
+  const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
+  if (!absorbed) {
     const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / h.energy) -
                                     (kMassNo - 1.0) * sqrt(h.energy / e_new));
     const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
@@ -434,7 +527,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
     h.energy = e_new;
   }
 
-  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
+  lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
   macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
 
   double rn0, rn1;
