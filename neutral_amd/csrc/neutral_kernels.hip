@@ -321,14 +321,7 @@ void history_regroup_kernel(SolveArgs a) {
    * ring; all wave-uniform */
   const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare);
   const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
-#if defined(NEUTRAL_EXP_CONTIGUOUS_SHARES)
-  /* experiment: wave w owns the contiguous block [w * per, (w + 1) * per) */
-  const int per = (nwork + nwaves - 1) / nwaves;
-  const int first = gw * per;
-  const int share = (pooled && first < nwork) ? ((first + per <= nwork) ? per : nwork - first) : 0;
-#else
   const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
-#endif
   int ring_head = 0;      /* ring position of the oldest waiting history, in [0, share) */
   int ring_count = share; /* histories waiting in the ring */
   int slice = 0;
@@ -336,11 +329,7 @@ void history_regroup_kernel(SolveArgs a) {
   unsigned w_collide_passes = 0;
   /* ring position -> queue entry (pos < 2 * share) */
   auto ring_slot = [&](int pos) -> unsigned* {
-#if defined(NEUTRAL_EXP_CONTIGUOUS_SHARES)
-    return a.queue + ((size_t)first + (size_t)((pos >= share) ? pos - share : pos));
-#else
     return a.queue + ((size_t)gw + (size_t)((pos >= share) ? pos - share : pos) * (size_t)nwaves);
-#endif
   };
   if (pooled) {
     drained = (share == 0);
