@@ -54,6 +54,8 @@ struct History {
    * for the two quotients of a facet crossing, and whether each may be used */
   double r_speed, r_cell_mfp;
   int plain_div; /* bit 0: speed, bit 1: cell_mfp inside the plain division range */
+  /* collision kernel only: this history's Threefry key schedule (see ThreefryKey) */
+  ThreefryKey key;
   unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
   unsigned nevents; /* events of this history so far: watchdog only */
@@ -480,7 +482,7 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables, typename IndexPtr, typename Tally>
+template <bool kSameTables, bool kKeptKey = false, typename IndexPtr, typename Tally>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
                                         const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
@@ -492,7 +494,11 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   const double p_absorb = kSameTables ? half_or_quotient(h.macro_a, h.macro_s + h.macro_a)
                                       : h.macro_a / (h.macro_s + h.macro_a);
   double rc0, rc1;
-  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
+  if (kKeptKey) {
+    generate_random_numbers(h.key, a.master_key, h.counter++, rc0, rc1);
+  } else {
+    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
+  }
 
   const bool absorbed = (rc0 < p_absorb);
   if (absorbed) {
@@ -531,7 +537,11 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
 
   double rn0, rn1;
-  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
+  if (kKeptKey) {
+    generate_random_numbers(h.key, a.master_key, h.counter++, rn0, rn1);
+  } else {
+    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
+  }
   h.mfp_to_collision = -log(rn0) / h.macro_s;
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);
