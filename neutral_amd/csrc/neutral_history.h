@@ -444,13 +444,16 @@ __device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, i
 
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far.
  * `e` holds the edges of the history's cell: a collision leaves the cell alone, so
- * the collision kernel loads them once per cell instead of once per event. */
+ * the collision kernel loads them once per cell instead of once per event.
+ * kWatchdog = false: the caller counts events and applies the watchdog itself (the
+ * stream kernel does so once per pass of up to 16 facets instead of once per facet). */
+template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const CellEdges& e) {
   if (!(h.dt_to_census > 0.0)) {
     h.ev = kEvEnd;
     return;
   }
-  if (++h.nevents > kMaxEventsPerHistory) {
+  if (kWatchdog && ++h.nevents > kMaxEventsPerHistory) {
     atomicAdd(&a.counters->aborted, 1u);
     h.ev = kEvEnd;
     return;
@@ -469,15 +472,16 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const Cel
                         : (crosses ? distance_to_facet : distance_to_census);
 }
 
+template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 #if defined(NEUTRAL_EXP_COMPUTED_EDGES)
   /* timing experiment only: no edge loads */
   const double ew = 1.0 / (double)a.nx;
   const int ex = h.cellx - a.x_off + a.pad;
   const int ey = h.celly - a.y_off + a.pad;
-  decide(h, a, CellEdges{ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew});
+  decide<kWatchdog>(h, a, CellEdges{ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew});
 #else
-  decide(h, a, load_edges(a, h.cellx, h.celly));
+  decide<kWatchdog>(h, a, load_edges(a, h.cellx, h.celly));
 #endif
 }
 

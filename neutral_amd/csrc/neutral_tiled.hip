@@ -459,6 +459,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
          * ~100 scalar instructions; histories cross ~60 facets in a row), or the
          * end of the history */
         if (h.ev == kEvFacet) {
+          int crossed = kStreamRepeat; /* facets this lane crosses in this pass */
 #pragma unroll 1
           for (int rep = 0; rep < kStreamRepeat; ++rep) {
             /* outside the window with a long way to go: continue in the pass that
@@ -472,17 +473,27 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
             if (leave) {
               park = kRecMigrate;
+              crossed = rep;
               break;
             }
-            nfacets++;
             cross_facet<true>(h, a, tally);
-            decide(h, a);
+            decide<false>(h, a);
             if (h.ev != kEvFacet) {
               if (h.ev == kEvCollision) {
                 park = kRecCollide;
               }
+              crossed = rep + 1;
               break;
             }
+          }
+          /* facets are counted, and the event watchdog applied, once per pass (the
+           * loop counter is scalar: per facet they cost three vector and half a
+           * dozen scalar instructions) */
+          nfacets += (unsigned)crossed;
+          h.nevents += (unsigned)crossed;
+          if (h.nevents > kMaxEventsPerHistory && h.ev == kEvFacet) {
+            atomicAdd(&a.counters->aborted, 1u);
+            h.ev = kEvEnd; /* ended like a history whose time has run out, next pass */
           }
         } else {
           if (h.ev == kEvCensus) {
