@@ -116,6 +116,29 @@ struct WindowTally {
   }
 };
 
+/* The same destination for a cell whose window coordinates the caller has already
+ * worked out (the stream kernel needs them anyway, to decide whether a particle
+ * that left the window should wait for the next pass). */
+struct WindowCellTally {
+  lds_double* window;
+  unsigned lx, ly; /* cell - window origin; >= W outside the window */
+  int W;
+  __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
+                                             double energy_deposition) const {
+    const double v = energy_deposition * a.inv_ntotal_particles;
+#if defined(NEUTRAL_EXP_NO_TALLY)
+    if (v == 1.2345e300) window[0] = v; /* timing experiment only */
+    return;
+#endif
+    if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
+      (void)__hip_atomic_fetch_add(&window[ly * (unsigned)W + lx], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      unsafeAtomicAdd(&a.tally[(pcelly - a.y_off) * a.nx + (pcellx - a.x_off)], v);
+    }
+  }
+};
+
 /* Where a kernel variant keeps the bucketed cs indexes: K1 reads them from
  * global memory (L1/L2 hits), the persistent K2 stages them in LDS once per
  * workgroup.  A null pointer means "no index": plain bisection. */

@@ -465,7 +465,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             /* outside the window with a long way to go: continue in the pass that
              * centres a window on wherever the particle is by then */
             bool leave = false;
-            if (windowed && t.allow_migrate && !tally.inside(a, h.cellx, h.celly)) {
+            const WindowCellTally cell_tally{tally.window,
+                                             (unsigned)(h.cellx - a.x_off - tally.ox),
+                                             (unsigned)(h.celly - a.y_off - tally.oy), kWindow};
+            const bool in_window = (cell_tally.lx < (unsigned)kWindow) &
+                                   (cell_tally.ly < (unsigned)kWindow);
+            if (windowed && t.allow_migrate && !in_window) {
               const double ahead = h.speed * h.dt_to_census;
               const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
                                                    fabs(h.omega_y) * t.cells_per_y);
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               crossed = rep;
               break;
             }
-            cross_facet<true>(h, a, tally);
+            cross_facet<true>(h, a, cell_tally); /* tallies the cell it leaves: this one */
             decide<false>(h, a);
             if (h.ev != kEvFacet) {
               if (h.ev == kEvCollision) {
