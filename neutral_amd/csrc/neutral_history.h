@@ -472,14 +472,20 @@ __device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, i
  * stream kernel does so once per pass of up to 16 facets instead of once per facet). */
 template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const CellEdges& e) {
-  if (!(h.dt_to_census > 0.0)) {
-    h.ev = kEvEnd;
-    return;
-  }
-  if (kWatchdog && ++h.nevents > kMaxEventsPerHistory) {
-    atomicAdd(&a.counters->aborted, 1u);
-    h.ev = kEvEnd;
-    return;
+  /* the loop condition of :134.  Without the watchdog the whole function is a pure
+   * computation, so it runs for every lane and the condition becomes a select at
+   * the end (no exec-mask region in the stream kernel's facet loop) */
+  const bool running = (h.dt_to_census > 0.0);
+  if (kWatchdog) {
+    if (!running) {
+      h.ev = kEvEnd;
+      return;
+    }
+    if (++h.nevents > kMaxEventsPerHistory) {
+      atomicAdd(&a.counters->aborted, 1u);
+      h.ev = kEvEnd;
+      return;
+    }
   }
   double distance_to_facet;
   calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
@@ -493,6 +499,9 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const Cel
   h.ev = collides ? kEvCollision : (crosses ? kEvFacet : kEvCensus);
   h.distance = collides ? distance_to_collision
                         : (crosses ? distance_to_facet : distance_to_census);
+  if (!kWatchdog) {
+    h.ev = running ? h.ev : (int)kEvEnd;
+  }
 }
 
 template <bool kWatchdog = true>
