@@ -459,10 +459,20 @@ struct CellEdges {
   double x_lo, x_hi, y_lo, y_hi;
 };
 
+/* element `index` (>= 0) of a mesh array through an unsigned 32-bit byte offset: the
+ * load then takes its base from scalar registers and one shifted vector register,
+ * where a signed 64-bit index costs a sign extension and a 64-bit add per access
+ * (mesh arrays are far below 4 GB: 128 MB at 4000^2) */
+__device__ __forceinline__ const double* mesh_element(const double* base, int index) {
+  return (const double*)((const char*)base + ((unsigned)index << 3));
+}
+
 __device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, int celly) {
   const int ex = cellx - a.x_off + a.pad;
   const int ey = celly - a.y_off + a.pad;
-  return CellEdges{a.edgex[ex], a.edgex[ex + 1], a.edgey[ey], a.edgey[ey + 1]};
+  const double* px = mesh_element(a.edgex, ex);
+  const double* py = mesh_element(a.edgey, ey);
+  return CellEdges{px[0], px[1], py[0], py[1]};
 }
 
 /* loop head, omp3/neutral.c:134-150,170: which event comes next, and how far.
@@ -615,7 +625,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 #if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
   const double new_density = h.local_density; /* timing experiment only (uniform decks) */
 #else
-  const double new_density = a.density[(ncelly - a.y_off) * a.nx + (ncellx - a.x_off)];
+  const double new_density =
+      *mesh_element(a.density, (ncelly - a.y_off) * a.nx + (ncellx - a.x_off));
 #endif
 
   const double distance_to_facet = h.distance;
