@@ -152,6 +152,14 @@ __device__ __forceinline__ void generate_random_numbers(const ThreefryKey& key,
   rn1 = u64_to_unit(r1);
 }
 
+/* element `index` (>= 0) of an f64 array through an unsigned 32-bit byte offset: the
+ * load then takes its base from scalar registers and one shifted vector register,
+ * where a signed 64-bit index costs a sign extension and a 64-bit add per access
+ * (mesh arrays and tables are far below 4 GB: 128 MB at 4000^2) */
+__device__ __forceinline__ const double* mesh_element(const double* base, int index) {
+  return (const double*)((const char*)base + ((unsigned)index << 3));
+}
+
 /* ---- cross-section tables -------------------------------------------------- */
 
 struct CsTable {
@@ -207,7 +215,7 @@ __device__ __forceinline__ int cs_bracket_indexed(const double* __restrict__ key
   hi = (hi > n - 1) ? n - 1 : hi;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (energy < keys[mid]) {
+    if (energy < *mesh_element(keys, mid)) {
       hi = mid;
     } else {
       lo = mid;
@@ -219,10 +227,12 @@ __device__ __forceinline__ int cs_bracket_indexed(const double* __restrict__ key
 __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys,
                                                  const double* __restrict__ values,
                                                  int ind, double energy) {
-  const double k0 = keys[ind];
-  const double k1 = keys[ind + 1];
-  const double v0 = values[ind];
-  const double v1 = values[ind + 1];
+  const double* k = mesh_element(keys, ind);
+  const double* v = mesh_element(values, ind);
+  const double k0 = k[0];
+  const double k1 = k[1];
+  const double v0 = v[0];
+  const double v1 = v[1];
   return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
 }
 

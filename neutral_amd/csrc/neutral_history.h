@@ -209,7 +209,7 @@ __device__ __forceinline__ BracketSearch bracket_begin(const double* __restrict_
     s.hi = n - 1;
   }
   s.mid = (s.lo + s.hi) >> 1;
-  s.kmid = keys[s.mid]; /* lo <= mid <= hi: a valid entry even when no probe is needed */
+  s.kmid = *mesh_element(keys, s.mid); /* lo <= mid <= hi: valid even when no probe is needed */
   return s;
 }
 
@@ -226,7 +226,7 @@ __device__ __forceinline__ int bracket_finish(const double* __restrict__ keys,
   }
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (energy < keys[mid]) {
+    if (energy < *mesh_element(keys, mid)) {
       hi = mid;
     } else {
       lo = mid;
@@ -459,13 +459,6 @@ struct CellEdges {
   double x_lo, x_hi, y_lo, y_hi;
 };
 
-/* element `index` (>= 0) of a mesh array through an unsigned 32-bit byte offset: the
- * load then takes its base from scalar registers and one shifted vector register,
- * where a signed 64-bit index costs a sign extension and a 64-bit add per access
- * (mesh arrays are far below 4 GB: 128 MB at 4000^2) */
-__device__ __forceinline__ const double* mesh_element(const double* base, int index) {
-  return (const double*)((const char*)base + ((unsigned)index << 3));
-}
 
 __device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, int celly) {
   const int ex = cellx - a.x_off + a.pad;
