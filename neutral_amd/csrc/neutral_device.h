@@ -159,6 +159,9 @@ __device__ __forceinline__ void generate_random_numbers(const ThreefryKey& key,
 __device__ __forceinline__ const double* mesh_element(const double* base, int index) {
   return (const double*)((const char*)base + ((unsigned)index << 3));
 }
+__device__ __forceinline__ double* mesh_element(double* base, int index) {
+  return (double*)((char*)base + ((unsigned)index << 3));
+}
 
 /* ---- cross-section tables -------------------------------------------------- */
 

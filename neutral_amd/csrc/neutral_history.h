@@ -77,7 +77,7 @@ struct GlobalTally {
     /* timing experiment only: keep the value alive, drop the memory operation */
     if (energy_deposition == 1.2345e300) a.tally[celly * a.nx + cellx] = energy_deposition;
 #else
-    unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], energy_deposition * a.inv_ntotal_particles);
+    unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), energy_deposition * a.inv_ntotal_particles);
 #endif
   }
 };
@@ -111,7 +111,7 @@ struct WindowTally {
       (void)__hip_atomic_fetch_add(&window[ly * W + lx], v, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      unsafeAtomicAdd(&a.tally[celly * a.nx + cellx], v);
+      unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), v);
     }
   }
 };
@@ -134,7 +134,7 @@ struct WindowCellTally {
       (void)__hip_atomic_fetch_add(&window[ly * (unsigned)W + lx], v, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      unsafeAtomicAdd(&a.tally[(pcelly - a.y_off) * a.nx + (pcellx - a.x_off)], v);
+      unsafeAtomicAdd(mesh_element(a.tally, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
     }
   }
 };
