@@ -22,7 +22,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 2 /* 2: probe_division, NeutralHipStepStats grew requeued + collide_passes */
+#define NEUTRAL_ABI_VERSION 3 /* 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
 #define NEUTRAL_VALIDATE_TOLERANCE 1.0e-3 /* neutral_data.h:27 */
@@ -804,6 +804,14 @@ void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int
   HIP_CHECK(neutral::launch_probe_division(d_in, d_out, d_p, n, g.stream));
   stage_out(out2, d_out, (size_t)2 * n);
   stage_out(plain, d_p, (size_t)n);
+  HIP_CHECK(hipFree(d_in));
+}
+
+void neutral_hip_probe_log(const double* x, double* out2, int n) {
+  double* d_in = stage_in(x, (size_t)n);
+  double* d_out = stage_in((const double*)nullptr, (size_t)2 * n);
+  HIP_CHECK(neutral::launch_probe_log(d_in, d_out, n, g.stream));
+  stage_out(out2, d_out, (size_t)2 * n);
   HIP_CHECK(hipFree(d_in));
 }
 

@@ -239,6 +239,63 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
   return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
 }
 
+/* ---- log of a sample (omp3/neutral.c:131,295: mfp = -log(rn)/Sigma_s) -----------
+ * The device library's log() delivers a double-double result internally (it also
+ * serves pow) and costs ~95 vector instructions; a collision draws one log and is
+ * bound by vector issue.  This is the classical faithful evaluation in ~42:
+ *     x = 2^k * m, m in [sqrt(1/2), sqrt(2)),  f = m - 1,  s = f / (2 + f),  z = s^2
+ *     log(1+f) = 2s + s*R(z),  R(z) = sum_{j=1..10} 2/(2j+1) z^j   (|s| <= 0.1716: the
+ *                                      truncated tail is below 2^-60 of the result)
+ *     log(x)   = k*ln2_hi - ((f^2/2 - (s*(f^2/2 + R) + k*ln2_lo)) - f)
+ * with ln2 split so that k*ln2_hi is exact.  Error below 1 ulp (measured on the
+ * device against an 80-bit reference: tests/test_hip_parity.py), like the libm the
+ * reference links -- the log is the one operation of this path that is NOT
+ * identical between conforming math libraries, and event counts have never
+ * depended on its last bit (section 3 of DESIGN.md).  Samples lie in [2^-65, 1];
+ * zero, negative, subnormal, infinite and NaN arguments get log()'s answers from a
+ * rare branch. */
+__device__ __forceinline__ double log_of_sample(double x) {
+  int k_scaled = 0;
+  if (__builtin_expect(!((x >= 2.2250738585072014e-308) & (x <= 1.7976931348623157e308)), 0)) {
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    if (x == 0.0) {
+      return -__builtin_huge_val();
+    }
+    if (!(x > 0.0)) {
+      return __builtin_nan(""); /* negative or NaN */
+    }
+    if (x > 1.7976931348623157e308) {
+      return x; /* +inf */
+    }
+    x *= 18014398509481984.0; /* subnormal: scaled by 2^54 */
+    k_scaled = -54;
+  }
+  double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
+  int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
+  const bool low = (m < 0.70710678118654752440);
+  m = low ? m + m : m; /* [sqrt(1/2), sqrt(2)) */
+  k = low ? k - 1 : k;
+  const double f = m - 1.0; /* exact */
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  double r = 2.0 / 21.0;
+  r = __builtin_fma(r, z, 2.0 / 19.0);
+  r = __builtin_fma(r, z, 2.0 / 17.0);
+  r = __builtin_fma(r, z, 2.0 / 15.0);
+  r = __builtin_fma(r, z, 2.0 / 13.0);
+  r = __builtin_fma(r, z, 2.0 / 11.0);
+  r = __builtin_fma(r, z, 2.0 / 9.0);
+  r = __builtin_fma(r, z, 2.0 / 7.0);
+  r = __builtin_fma(r, z, 2.0 / 5.0);
+  r = __builtin_fma(r, z, 2.0 / 3.0);
+  r = r * z;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  constexpr double ln2_hi = 0.6931471803691238;     /* 0x3fe62e42fee00000: 32 significant bits */
+  constexpr double ln2_lo = 1.9082149292705877e-10; /* ln 2 - ln2_hi */
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + dk * ln2_lo)) - f);
+}
+
 /* ---- quotients by a denominator that many numerators share --------------------
  * A facet crossing divides its path length by the speed and by the mean free
  * path of the cell (omp3/neutral.c:311-312), and neither changes from one vacuum

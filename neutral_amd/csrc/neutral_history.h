@@ -427,7 +427,7 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   h.dt_to_census = a.dt;
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  h.mfp_to_collision = -log(rn0) / h.macro_s;
+  h.mfp_to_collision = -log_of_sample(rn0) / h.macro_s;
   refresh_direction(h);
   refresh_deposition_terms<kSameTables>(h);
 }
@@ -581,7 +581,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   } else {
     generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   }
-  h.mfp_to_collision = -log(rn0) / h.macro_s;
+  h.mfp_to_collision = -log_of_sample(rn0) / h.macro_s;
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);
   refresh_direction(h);

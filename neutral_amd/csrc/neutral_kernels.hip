@@ -610,6 +610,20 @@ __global__ __launch_bounds__(kBlock) void probe_division_kernel(const double* in
   }
 }
 
+__global__ __launch_bounds__(kBlock) void probe_log_kernel(const double* in, double* out, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    out[2 * i] = log_of_sample(in[i]); /* what the history kernels use */
+    out[2 * i + 1] = log(in[i]);       /* the device library's */
+  }
+}
+
+hipError_t launch_probe_log(const double* in, double* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_log_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                     in, out, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_probe_division(const double* in, double* out, int* plain, int n,
                                  hipStream_t stream) {
   hipLaunchKernelGGL(probe_division_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,

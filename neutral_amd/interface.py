@@ -83,6 +83,7 @@ ABI_SYMBOLS = (
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
     "neutral_hip_probe_distance_to_facet", "neutral_hip_probe_division",
+    "neutral_hip_probe_log",
 )
 
 _lib = C.CDLL(LIB_PATH)
@@ -127,6 +128,7 @@ _lib.neutral_hip_probe_threefry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, 
 _lib.neutral_hip_probe_cs_lookup.argtypes = [C.POINTER(CrossSection), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 _lib.neutral_hip_probe_division.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+_lib.neutral_hip_probe_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_distance_to_facet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int]
 
@@ -248,6 +250,14 @@ def probe_division(rows: np.ndarray):
     _lib.neutral_hip_probe_division(a.ctypes.data, out.ctypes.data, plain.ctypes.data,
                                     a.shape[0])
     return out[:, 0], out[:, 1], plain.astype(bool)
+
+
+def probe_log(x: np.ndarray):
+    """x -> (the kernels' log of a sample, the device library's log)"""
+    a = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.zeros((a.size, 2), dtype=np.float64)
+    _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
+    return out[:, 0], out[:, 1]
 
 
 def probe_distance_to_facet(rows: np.ndarray):

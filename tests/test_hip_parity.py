@@ -177,6 +177,36 @@ def test_quotient_through_kept_reciprocal_is_the_ieee_quotient(iface):
     assert np.array_equal(q_kept[plain].view(np.uint64), q_dev[plain].view(np.uint64))
 
 
+def test_log_of_a_sample_is_faithful(iface):
+    """The history kernels take -log of a (0,1] sample with their own evaluation
+    (neutral_device.h: log_of_sample) instead of the device library's.  Measured here
+    against an 80-bit reference: below one ulp everywhere (a faithful result, what
+    libm promises), correct at the ends of the sample range, and it agrees with the
+    device library to the last bit or its neighbour."""
+    rng = np.random.default_rng(42)
+    n = 2_000_000
+    x = np.concatenate([
+        rng.random(n),                                   # the bulk of the samples
+        1.0 - rng.random(n // 4) * 2.0 ** -rng.integers(1, 52, n // 4),   # just below one
+        np.ldexp(rng.random(n // 4) + 1.0, -rng.integers(1, 66, n // 4).astype(np.int32)),
+        np.array([1.0, 0.5, 2.0 ** -65, 2.0 ** -64 + 2.0 ** -65, np.nextafter(1.0, 0.0),
+                  0.70710678118654746, 0.70710678118654757, 3.0, 1e300, 2.5e-308]),
+    ])
+    x = x[(x > 0.0)]
+    mine, lib = iface.probe_log(x)
+    ref = np.log(x.astype(np.longdouble))
+    ulp = np.spacing(np.abs(ref.astype(np.float64))).astype(np.longdouble)
+    ulp[ulp == 0] = np.longdouble(5e-324)
+    err = np.abs(mine.astype(np.longdouble) - ref) / ulp
+    assert float(err.max()) < 1.0, float(err.max())
+    assert np.all(mine[x == 1.0] == 0.0) and (x == 1.0).any()
+    # the library's result is the same double or the next one
+    step = np.abs(mine.view(np.int64) - lib.view(np.int64))
+    assert int(step.max()) <= 1
+    print("log_of_sample: max error %.3f ulp, %.2f %% differ from the library by one ulp"
+          % (float(err.max()), 100.0 * float((step == 1).mean())))
+
+
 @pytest.mark.parametrize("deck", ["scatter", "stream", "csp", "split"])
 def test_inject_matches_oracle(iface, make_problem, cs, deck):
     prob = make_problem(deck, nx=100, nparticles=30000, iterations=1)
