@@ -35,15 +35,15 @@ constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
  * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  K2
- * needs ~147 without spilling; the two instantiations make opposite choices, see
- * history_regroup_kernel (profiles/r01e/baseline_configs.log).  The collision
- * stage is bound by vector issue: at 4 waves (56 B of scratch) it runs exactly as
- * fast as at 3 (profiles/r01g). */
+ * needs ~155 without spilling.  Both instantiations run at 3: the kernel is bound
+ * by vector issue, and at 4 waves the spills (96 B of scratch since the state kept
+ * per history grew) cost variant 1 6-20 % (profiles/r01g/baseline_configs.log;
+ * the collision stage ran exactly as fast at 4 as at 3 when it spilled 56 B). */
 #ifndef NEUTRAL_K1_WAVES
 #define NEUTRAL_K1_WAVES 3
 #endif
 #ifndef NEUTRAL_K2_WAVES
-#define NEUTRAL_K2_WAVES 4
+#define NEUTRAL_K2_WAVES 3
 #endif
 #ifndef NEUTRAL_K2_QUEUE_WAVES
 #define NEUTRAL_K2_QUEUE_WAVES 3
