@@ -239,6 +239,33 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
   return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
 }
 
+/* ---- square root without the wrapping ---------------------------------------------
+ * The compiler's IEEE sqrt is v_rsq_f64 and two Goldschmidt steps plus a residual
+ * correction (ten operations) wrapped in a scaling of tiny arguments (compare, two
+ * ldexp, select) and a class test for zero and infinity.  The path's four roots
+ * per collision take arguments that are zero or lie in [1e-17, 1e16]: for anything
+ * in [2^-500, 2^500] the wrapping is the identity, so the ten operations alone
+ * give the same correctly rounded bits (tested against numpy on the device,
+ * tests/test_hip_parity.py); zero is answered directly and everything else goes
+ * to the ordinary sqrt. */
+__device__ __forceinline__ double sqrt_plain_range(double x) {
+  const unsigned hi = (unsigned)__double2hiint(x);
+  if (__builtin_expect(!((hi - (523u << 20)) < (1000u << 20)), 0)) { /* also negative, NaN, inf, 0 */
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    return sqrt(x);
+  }
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g0 = x * y;
+  const double h0 = 0.5 * y;
+  const double r0 = __builtin_fma(-h0, g0, 0.5);
+  const double g1 = __builtin_fma(g0, r0, g0);
+  const double h1 = __builtin_fma(h0, r0, h0);
+  const double d0 = __builtin_fma(-g1, g1, x);
+  const double g2 = __builtin_fma(d0, h1, g1);
+  const double d1 = __builtin_fma(-g2, g2, x);
+  return __builtin_fma(d1, h1, g2);
+}
+
 /* ---- log of a sample (omp3/neutral.c:131,295: mfp = -log(rn)/Sigma_s) -----------
  * The device library's log() delivers a double-double result internally (it also
  * serves pow) and costs ~95 vector instructions; a collision draws one log and is
@@ -366,7 +393,7 @@ __device__ __forceinline__ double calculate_energy_deposition(
 }
 
 __device__ __forceinline__ double speed_of(double energy) {
-  return sqrt((2.0 * energy * kEvToJ) / kParticleMass); /* omp3/neutral.c:117,297 */
+  return sqrt_plain_range((2.0 * energy * kEvToJ) / kParticleMass); /* omp3/neutral.c:117,297 */
 }
 
 }  // namespace neutral

@@ -562,9 +562,9 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   }
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {
-    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / h.energy) -
-                                    (kMassNo - 1.0) * sqrt(h.energy / e_new));
-    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt_plain_range(e_new / h.energy) -
+                                    (kMassNo - 1.0) * sqrt_plain_range(h.energy / e_new));
+    const double sin_theta = sqrt_plain_range(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
     h.omega_x = omega_x_new;

@@ -613,8 +613,10 @@ __global__ __launch_bounds__(kBlock) void probe_division_kernel(const double* in
 __global__ __launch_bounds__(kBlock) void probe_log_kernel(const double* in, double* out, int n) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) {
-    out[2 * i] = log_of_sample(in[i]); /* what the history kernels use */
-    out[2 * i + 1] = log(in[i]);       /* the device library's */
+    out[4 * i] = log_of_sample(in[i]); /* what the history kernels use */
+    out[4 * i + 1] = log(in[i]);       /* the device library's */
+    out[4 * i + 2] = sqrt_plain_range(in[i]);
+    out[4 * i + 3] = sqrt(in[i]);
   }
 }
 

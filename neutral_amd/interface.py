@@ -255,9 +255,17 @@ def probe_division(rows: np.ndarray):
 def probe_log(x: np.ndarray):
     """x -> (the kernels' log of a sample, the device library's log)"""
     a = np.ascontiguousarray(x, dtype=np.float64).ravel()
-    out = np.zeros((a.size, 2), dtype=np.float64)
+    out = np.zeros((a.size, 4), dtype=np.float64)
     _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
     return out[:, 0], out[:, 1]
+
+
+def probe_sqrt(x: np.ndarray):
+    """x -> (the kernels' square root, the compiler's sqrt)"""
+    a = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.zeros((a.size, 4), dtype=np.float64)
+    _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
+    return out[:, 2], out[:, 3]
 
 
 def probe_distance_to_facet(rows: np.ndarray):

@@ -207,6 +207,30 @@ def test_log_of_a_sample_is_faithful(iface):
           % (float(err.max()), 100.0 * float((step == 1).mean())))
 
 
+def test_square_root_without_the_wrapping_is_the_ieee_root(iface):
+    """neutral_device.h: sqrt_plain_range keeps the compiler's ten-operation core of
+    the f64 square root and leaves its range scaling out for arguments in
+    [2^-500, 2^500]: the bits must be numpy's (correctly rounded) everywhere, inside
+    the range, outside it and for the special values."""
+    rng = np.random.default_rng(9)
+    n = 2_000_000
+    mant = rng.random(n) + 1.0
+    hard = np.where(rng.integers(0, 3, n) == 0, 2.0 - np.ldexp(1.0, -rng.integers(0, 52, n)), mant)
+    x = np.concatenate([
+        np.ldexp(hard, rng.integers(-499, 499, n).astype(np.int32)),
+        1.0 - rng.random(n // 2) ** 2,                   # sin^2 of a scattering angle
+        1.0 + rng.random(n // 2) * 0.05,                 # energy ratios
+        np.ldexp(mant[: n // 4], rng.integers(-1070, 1023, n // 4).astype(np.int32)),
+        np.array([0.0, -0.0, 1.0, 4.0, np.inf, 5e-324, 2.0 ** -500, 2.0 ** 500, 1e-320]),
+    ])
+    mine, dev = iface.probe_sqrt(x)
+    ref = np.sqrt(x)
+    assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64))
+    assert np.array_equal(mine.view(np.uint64), ref.view(np.uint64))
+    neg = iface.probe_sqrt(np.array([-1.0, np.nan]))[0]
+    assert np.isnan(neg).all()
+
+
 @pytest.mark.parametrize("deck", ["scatter", "stream", "csp", "split"])
 def test_inject_matches_oracle(iface, make_problem, cs, deck):
     prob = make_problem(deck, nx=100, nparticles=30000, iterations=1)
