@@ -245,10 +245,13 @@ void neutral_hip_probe_distance_to_facet(const double* in9, double* distance, in
  *              form of omp3/neutral.c:311-312)}; plain[i] = 1 when both operands lie
  *              in the range where the kernel uses the second form */
 void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int n);
-/*   log:       out4 = n rows {the logarithm the history kernels take of a sample
+/*   log:       out8 = n rows {the logarithm the history kernels take of a sample
  *              (omp3/neutral.c:131,295), the device library's log, the kernels'
- *              square root (:255-259,297), the compiler's sqrt} of x[i] */
-void neutral_hip_probe_log(const double* x, double* out4, int n);
+ *              square root (:255-259,297), the compiler's sqrt} of x[i], followed by
+ *              n rows {x / PARTICLE_MASS the kernels' way (:297), as the compiler
+ *              divides, x / (MASS_NO+1)^2 the kernels' way (:252), as the compiler
+ *              divides} */
+void neutral_hip_probe_log(const double* x, double* out8, int n);
 /* Library/ABI version, bumped on any signature change. */
 int neutral_hip_abi_version(void);
 

@@ -807,11 +807,11 @@ void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int
   HIP_CHECK(hipFree(d_in));
 }
 
-void neutral_hip_probe_log(const double* x, double* out4, int n) {
+void neutral_hip_probe_log(const double* x, double* out8, int n) {
   double* d_in = stage_in(x, (size_t)n);
-  double* d_out = stage_in((const double*)nullptr, (size_t)4 * n);
+  double* d_out = stage_in((const double*)nullptr, (size_t)8 * n);
   HIP_CHECK(neutral::launch_probe_log(d_in, d_out, n, g.stream));
-  stage_out(out4, d_out, (size_t)4 * n);
+  stage_out(out8, d_out, (size_t)8 * n);
   HIP_CHECK(hipFree(d_in));
 }
 

@@ -357,6 +357,24 @@ __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, dou
   return __builtin_fma(rem, r, q0);
 }
 
+/* a / b for a compile-time constant b: with y = RN(1/b) (rounded correctly by the
+ * compiler) the three operations of quotient_by_reciprocal deliver the correctly
+ * rounded quotient (Markstein: q0 faithful, exact residual by fma, one correction
+ * with the correctly rounded reciprocal), i.e. the bits of a / b, for numerators
+ * in the plain range; others take the ordinary division.  Tested on the device
+ * against numpy for both constants of the collision (tests/test_hip_parity.py). */
+template <typename Tag>
+__device__ __forceinline__ double quotient_by_constant(double a, double b, double y) {
+  if (__builtin_expect(in_plain_division_range(a), 1)) {
+    return quotient_by_reciprocal(a, b, y);
+  }
+  asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+  return a / b;
+}
+struct ByParticleMass {};
+struct ByMassNoPlusOneSquared {};
+constexpr double kMassNoPlusOneSquared = (kMassNo + 1.0) * (kMassNo + 1.0);
+
 /* ---- geometry (omp3/neutral.c:423-471) ------------------------------------- */
 
 __device__ __forceinline__ void calc_distance_to_facet(
@@ -393,7 +411,9 @@ __device__ __forceinline__ double calculate_energy_deposition(
 }
 
 __device__ __forceinline__ double speed_of(double energy) {
-  return sqrt_plain_range((2.0 * energy * kEvToJ) / kParticleMass); /* omp3/neutral.c:117,297 */
+  /* omp3/neutral.c:117,297 */
+  return sqrt_plain_range(quotient_by_constant<ByParticleMass>(2.0 * energy * kEvToJ, kParticleMass,
+                                                                1.0 / kParticleMass));
 }
 
 }  // namespace neutral

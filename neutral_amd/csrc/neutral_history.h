@@ -557,8 +557,9 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   if (!absorbed) {
     /* elastic scatter off a nucleus of mass number A */
     const double mu_cm = 1.0 - 2.0 * rc1;
-    e_new = h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0) /
-            ((kMassNo + 1.0) * (kMassNo + 1.0));
+    e_new = quotient_by_constant<ByMassNoPlusOneSquared>(
+        h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared,
+        1.0 / kMassNoPlusOneSquared);
   }
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {

@@ -617,6 +617,13 @@ __global__ __launch_bounds__(kBlock) void probe_log_kernel(const double* in, dou
     out[4 * i + 1] = log(in[i]);       /* the device library's */
     out[4 * i + 2] = sqrt_plain_range(in[i]);
     out[4 * i + 3] = sqrt(in[i]);
+    /* the two constant denominators of the collision, both ways */
+    out[4 * n + 4 * i] = quotient_by_constant<ByParticleMass>(in[i], kParticleMass,
+                                                              1.0 / kParticleMass);
+    out[4 * n + 4 * i + 1] = in[i] / kParticleMass;
+    out[4 * n + 4 * i + 2] = quotient_by_constant<ByMassNoPlusOneSquared>(
+        in[i], kMassNoPlusOneSquared, 1.0 / kMassNoPlusOneSquared);
+    out[4 * n + 4 * i + 3] = in[i] / kMassNoPlusOneSquared;
   }
 }
 

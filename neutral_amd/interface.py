@@ -255,17 +255,26 @@ def probe_division(rows: np.ndarray):
 def probe_log(x: np.ndarray):
     """x -> (the kernels' log of a sample, the device library's log)"""
     a = np.ascontiguousarray(x, dtype=np.float64).ravel()
-    out = np.zeros((a.size, 4), dtype=np.float64)
+    out = np.zeros((2 * a.size, 4), dtype=np.float64)
     _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
-    return out[:, 0], out[:, 1]
+    return out[:a.size, 0], out[:a.size, 1]
 
 
 def probe_sqrt(x: np.ndarray):
     """x -> (the kernels' square root, the compiler's sqrt)"""
     a = np.ascontiguousarray(x, dtype=np.float64).ravel()
-    out = np.zeros((a.size, 4), dtype=np.float64)
+    out = np.zeros((2 * a.size, 4), dtype=np.float64)
     _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
-    return out[:, 2], out[:, 3]
+    return out[:a.size, 2], out[:a.size, 3]
+
+
+def probe_constant_quotients(x: np.ndarray):
+    """x -> (x / PARTICLE_MASS kernels' way, compiler's, x / (MASS_NO+1)^2 kernels' way, compiler's)"""
+    a = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.zeros((2 * a.size, 4), dtype=np.float64)
+    _lib.neutral_hip_probe_log(a.ctypes.data, out.ctypes.data, a.size)
+    q = out[a.size:]
+    return q[:, 0], q[:, 1], q[:, 2], q[:, 3]
 
 
 def probe_distance_to_facet(rows: np.ndarray):

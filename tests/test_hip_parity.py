@@ -207,6 +207,30 @@ def test_log_of_a_sample_is_faithful(iface):
           % (float(err.max()), 100.0 * float((step == 1).mean())))
 
 
+def test_quotients_by_the_two_constants_are_ieee_quotients(iface):
+    """x / PARTICLE_MASS (speed, omp3/neutral.c:297) and x / (MASS_NO+1)^2 (energy after a
+    scatter, :252) go through the correctly rounded reciprocal of the constant and one
+    residual correction (neutral_device.h: quotient_by_constant): the bits of the IEEE
+    quotient, for numerators the path produces and for everything else."""
+    rng = np.random.default_rng(77)
+    n = 2_000_000
+    mant = rng.random(n) + 1.0
+    hard = np.where(rng.integers(0, 3, n) == 0, 2.0 - np.ldexp(1.0, -rng.integers(0, 52, n)), mant)
+    x = np.concatenate([
+        np.ldexp(hard, rng.integers(-299, 299, n).astype(np.int32)),
+        rng.random(n // 2) * 3.2e-13,                    # 2 E eV_TO_J for E up to 1 MeV
+        10.0 ** rng.uniform(-2, 8, n // 2) * 10201.0,    # E (A^2 + 2 A mu + 1)
+        np.ldexp(mant[: n // 8], rng.integers(-1070, 1023, n // 8).astype(np.int32)),
+        np.array([0.0, -0.0, 1.0, np.inf, 5e-324, -3.0]),
+    ])
+    m_fast, m_dev, a_fast, a_dev = iface.probe_constant_quotients(x)
+    with np.errstate(all="ignore"):
+        m_ref = x / 1.674927471213e-27
+        a_ref = x / 10201.0
+    for got, ref in ((m_dev, m_ref), (m_fast, m_ref), (a_dev, a_ref), (a_fast, a_ref)):
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
 def test_square_root_without_the_wrapping_is_the_ieee_root(iface):
     """neutral_device.h: sqrt_plain_range keeps the compiler's ten-operation core of
     the f64 square root and leaves its range scaling out for arguments in
