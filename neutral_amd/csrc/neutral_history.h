@@ -573,16 +573,19 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
     h.energy = e_new;
   }
 
-  lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
-  macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
-
+  /* the draw for the next free flight (:293-295) needs nothing from the tables: it
+   * and its logarithm are worked out while the search is still in flight */
   double rn0, rn1;
   if (kKeptKey) {
     generate_random_numbers(h.key, a.master_key, h.counter++, rn0, rn1);
   } else {
     generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   }
-  h.mfp_to_collision = -log_of_sample(rn0) / h.macro_s;
+  const double minus_log_rn0 = -log_of_sample(rn0);
+
+  lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
+  h.mfp_to_collision = minus_log_rn0 / h.macro_s;
   h.dt_to_census -= distance_to_collision / h.speed;
   h.speed = speed_of(h.energy);
   refresh_direction(h);
