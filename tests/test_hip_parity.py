@@ -600,7 +600,7 @@ def _random_deck_text(rng):
     return "\n".join(lines) + "\n", its
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(64))
 def test_random_decks_match_oracle(iface, cs, tmp_path, monkeypatch, seed):
     """Differential run on decks nobody tuned for: random source and density boxes,
     non-square meshes, random particle counts, energies and timesteps, a random kernel
