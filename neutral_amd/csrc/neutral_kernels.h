@@ -145,6 +145,11 @@ struct TiledArgs {
   uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
+  /* finer bucketed index for the collision stage (identical tables only; null: none) */
+  const unsigned short* fine_index;
+  int fine_index_n;
+  long long fine_index_base;
+  int fine_index_shift;
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants */
   int chunk_particles;     /* particles one workgroup takes at a time */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */

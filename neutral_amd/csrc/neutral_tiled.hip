@@ -732,6 +732,12 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.slot_info = t.info_in;
   c.tiles_x = t.tiles_x;
   c.susp = t.susp;
+  if (t.fine_index && c.same_tables) {
+    c.scatter_index = t.fine_index;
+    c.scatter_index_n = t.fine_index_n;
+    c.scatter_index_base = t.fine_index_base;
+    c.index_shift = t.fine_index_shift;
+  }
   return launch_solve(c, kVariantEventSorted, stream);
 }
 
