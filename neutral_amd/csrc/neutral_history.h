@@ -472,7 +472,7 @@ __device__ __forceinline__ CellEdges load_edges(const SolveArgs& a, int cellx, i
  * `e` holds the edges of the history's cell: a collision leaves the cell alone, so
  * the collision kernel loads them once per cell instead of once per event.
  * kWatchdog = false: the caller counts events and applies the watchdog itself (the
- * stream kernel does so once per pass of up to 16 facets instead of once per facet). */
+ * stream kernel does so once per pass of up to 64 facets instead of once per facet). */
 template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const CellEdges& e) {
   /* the loop condition of :134.  Without the watchdog the whole function is a pure

@@ -71,8 +71,10 @@ constexpr int kChunkParticlesMin = 4096;
 #define NEUTRAL_STREAM_REFILL_MIN 56
 #endif
 constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
+/* facet crossings per STREAM pass (64: a csp history's whole flight of ~63 facets;
+ * -1..2 % against 16) */
 #ifndef NEUTRAL_STREAM_REPEAT
-#define NEUTRAL_STREAM_REPEAT 16
+#define NEUTRAL_STREAM_REPEAT 64
 #endif
 constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
 constexpr int kSortBlock = 256;
