@@ -89,7 +89,10 @@ enum Ctrl : int {
 constexpr int kMaxStreamPasses = 64;
 /* a history leaves its window for another pass only if about this many facet
  * crossings still lie ahead; shorter tails finish with global atomics */
-constexpr double kMigrateMinFacets = 8.0;
+#ifndef NEUTRAL_MIGRATE_MIN_FACETS
+#define NEUTRAL_MIGRATE_MIN_FACETS 8.0
+#endif
+constexpr double kMigrateMinFacets = NEUTRAL_MIGRATE_MIN_FACETS;
 /* a tile (or the last chunk of one) with fewer particles than this tallies straight
  * to HBM: flushing a 16 384-cell window costs more than the few atomics it would
  * save, and its particles never migrate.  Such tiles share chunks with their
