@@ -185,6 +185,15 @@ constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is pl
 #endif
 constexpr int kRefillMin = NEUTRAL_REFILL_MIN;   /* REFILL pass once this many lanes are empty */
 constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many lanes wait */
+/* ... in the collision stage of the tiled pipeline: every lane.  Its histories are
+ * colliders; the few that leak into a facet crossing or end are served (STREAM,
+ * REFILL) before the next collision pass, which then runs full (split -6 %, csp
+ * -1 %).  With streamers and colliders mixed (variant 1) the same rule starves the
+ * parked colliders (3-5x slower), hence the two thresholds. */
+#ifndef NEUTRAL_COLLIDE_MIN_QUEUE
+#define NEUTRAL_COLLIDE_MIN_QUEUE 64
+#endif
+constexpr int kCollideMinQueue = NEUTRAL_COLLIDE_MIN_QUEUE;
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
@@ -358,7 +367,7 @@ void history_regroup_kernel(SolveArgs a) {
      * together, so there the order does not matter and collisions keep priority. */
     if (!pooled && n_refill >= kRefillMin) {
       pass = kWantRefill;
-    } else if (n_collide >= kCollideMin) {
+    } else if (n_collide >= (kQueue ? kCollideMinQueue : kCollideMin)) {
       pass = kWantCollide;
     } else if (n_refill >= kRefillMin) {
       pass = kWantRefill;
