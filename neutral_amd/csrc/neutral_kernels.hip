@@ -185,15 +185,6 @@ constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is pl
 #endif
 constexpr int kRefillMin = NEUTRAL_REFILL_MIN;   /* REFILL pass once this many lanes are empty */
 constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many lanes wait */
-/* ... in the collision stage of the tiled pipeline: every lane.  Its histories are
- * colliders; the few that leak into a facet crossing or end are served (STREAM,
- * REFILL) before the next collision pass, which then runs full (split -6 %, csp
- * -1 %).  With streamers and colliders mixed (variant 1) the same rule starves the
- * parked colliders (3-5x slower), hence the two thresholds. */
-#ifndef NEUTRAL_COLLIDE_MIN_QUEUE
-#define NEUTRAL_COLLIDE_MIN_QUEUE 64
-#endif
-constexpr int kCollideMinQueue = NEUTRAL_COLLIDE_MIN_QUEUE;
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
@@ -355,22 +346,32 @@ void history_regroup_kernel(SolveArgs a) {
       break;
     }
 
-    /* Pass choice.  A collision costs ~7x a facet crossing, so collisions wait
-     * (parked in registers) until they fill most of the wave; cheap STREAM
-     * passes run as long as any lane wants one; REFILL runs once enough lanes
-     * are empty to amortise the prologue, or when nothing else can run. */
+    /* Pass choice. */
     int pass;
-    /* With the first-come queue an empty lane costs a 64th of every collision pass
-     * until it is refilled, and colliders only drop below kCollideMin once 17 lanes
-     * are empty: refilling as soon as kRefillMin are is worth 7-10 % on scatter and
-     * split (profiles/r01g/ablate_refillfirst*.log).  A pooled wave's histories end
-     * together, so there the order does not matter and collisions keep priority. */
-    if (!pooled && n_refill >= kRefillMin) {
-      pass = kWantRefill;
-    } else if (n_collide >= (kQueue ? kCollideMinQueue : kCollideMin)) {
-      pass = kWantCollide;
+    if (kQueue) {
+      /* The collision stage: its histories are colliders.  The few that leak into a
+       * facet crossing or reach the end of the step are served at once (a STREAM
+       * pass is cheap and returns them to the collision passes, which then run
+       * full: split -6...14 %); empty lanes are refilled once kRefillMin have
+       * gathered (each costs a 64th of every collision pass until then: refilling
+       * only when fewer than 48 lanes collide cost scatter 10 %); otherwise
+       * everyone collides. */
+      if (n_stream > 0) {
+        pass = kWantStream;
+      } else if (n_refill >= kRefillMin) {
+        pass = kWantRefill;
+      } else if (n_collide > 0) {
+        pass = kWantCollide;
+      } else {
+        pass = kWantRefill;
+      }
     } else if (n_refill >= kRefillMin) {
+      /* variant 1, streamers and colliders mixed: collisions wait (parked in registers)
+       * until they fill most of the wave; cheap STREAM passes run as long as any
+       * lane wants one */
       pass = kWantRefill;
+    } else if (n_collide >= kCollideMin) {
+      pass = kWantCollide;
     } else if (n_stream > 0) {
       pass = kWantStream;
     } else if (n_refill > 0) {
