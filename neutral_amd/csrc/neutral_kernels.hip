@@ -448,19 +448,30 @@ void history_regroup_kernel(SolveArgs a) {
       }
     } else if (pass == kWantCollide) {
       /* ---- COLLIDE pass ---- */
-      w_collide_passes++;
-      if (want == kWantCollide) {
-        ncollisions++;
-        if (collide<kSameTables, kQueue>(h, a, ix, tally)) {
-          put_back<kQueue>(h, a, pid);
-          want = kWantRefill;
-        } else {
-          next_event(false);
-          want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+      /* In the collision stage the same lanes usually want the next pass as well: as
+       * long as nobody's wish changes (no death, no facet, no end of step) and no
+       * time slice ends, the passes follow each other without the three ballots
+       * and the pass choice above. */
+      bool slice_ends = false;
+      for (;;) {
+        w_collide_passes++;
+        if (want == kWantCollide) {
+          ncollisions++;
+          if (collide<kSameTables, kQueue>(h, a, ix, tally)) {
+            put_back<kQueue>(h, a, pid);
+            want = kWantRefill;
+          } else {
+            next_event(false);
+            want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+          }
+        }
+        slice_ends = pooled && ++slice >= kSlicePasses && ring_count > 0 &&
+                     (kSliceWindow == 0 || ring_count <= kSliceWindow);
+        if (!kQueue || slice_ends || __ballot(want == kWantCollide) != m_collide) {
+          break;
         }
       }
-      if (pooled && ++slice >= kSlicePasses && ring_count > 0 &&
-          (kSliceWindow == 0 || ring_count <= kSliceWindow)) {
+      if (slice_ends) {
         /* ---- end of a time slice: colliders swap with the waiting histories ---- */
         slice = 0;
         const bool out = (want == kWantCollide);
