@@ -82,44 +82,6 @@ __device__ __forceinline__ void threefry2x64_20(uint64_t c0, uint64_t k0,
   r1 = b;
 }
 
-/* The key schedule of one (pkey, master_key) pair: the five injections add
- * k[(s)%3] and k[(s+1)%3]+s (threefry.h:213-257), which do not depend on the
- * counter.  A history draws up to thousands of numbers from one key per timestep;
- * the collision kernel keeps the per-lane sums in registers (the master_key terms
- * are wave-uniform and live on the scalar unit anyway). */
-struct ThreefryKey {
-  uint64_t k0, k2, k2p1, k0p2, k2p4, k0p5;
-};
-
-__device__ __forceinline__ ThreefryKey threefry_key(uint64_t k0, uint64_t k1) {
-  ThreefryKey k;
-  k.k0 = k0;
-  k.k2 = 0x1BD11BDAA9FC1A22ull ^ k0 ^ k1;
-  k.k2p1 = k.k2 + 1;
-  k.k0p2 = k0 + 2;
-  k.k2p4 = k.k2 + 4;
-  k.k0p5 = k0 + 5;
-  return k;
-}
-
-/* threefry2x64_20 with the schedule supplied: same operations on the same values */
-__device__ __forceinline__ void threefry2x64_20(uint64_t c0, const ThreefryKey& k, uint64_t k1,
-                                                uint64_t& r0, uint64_t& r1) {
-  uint64_t a = c0 + k.k0;
-  uint64_t b = k1;
-  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
-  a += k1; b += k.k2p1;
-  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(32) NEUTRAL_TF_ROUND(24) NEUTRAL_TF_ROUND(21)
-  a += k.k2; b += k.k0p2;
-  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
-  a += k.k0; b += k1 + 3;
-  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(32) NEUTRAL_TF_ROUND(24) NEUTRAL_TF_ROUND(21)
-  a += k1; b += k.k2p4;
-  NEUTRAL_TF_ROUND(16) NEUTRAL_TF_ROUND(42) NEUTRAL_TF_ROUND(12) NEUTRAL_TF_ROUND(31)
-  a += k.k2; b += k.k0p5;
-  r0 = a;
-  r1 = b;
-}
 #undef NEUTRAL_TF_ROUND
 
 /* u64 -> (0,1]: round-to-nearest conversion, then *2^-64 + 2^-65
@@ -139,15 +101,6 @@ __device__ __forceinline__ void generate_random_numbers(uint64_t pkey,
                                                         double& rn1) {
   uint64_t r0, r1;
   threefry2x64_20(counter, pkey, master_key, r0, r1);
-  rn0 = u64_to_unit(r0);
-  rn1 = u64_to_unit(r1);
-}
-
-__device__ __forceinline__ void generate_random_numbers(const ThreefryKey& key,
-                                                        uint64_t master_key, uint64_t counter,
-                                                        double& rn0, double& rn1) {
-  uint64_t r0, r1;
-  threefry2x64_20(counter, key, master_key, r0, r1);
   rn0 = u64_to_unit(r0);
   rn1 = u64_to_unit(r1);
 }

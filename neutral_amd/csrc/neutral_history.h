@@ -54,8 +54,6 @@ struct History {
    * for the two quotients of a facet crossing, and whether each may be used */
   double r_speed, r_cell_mfp;
   int plain_div; /* bit 0: speed, bit 1: cell_mfp inside the plain division range */
-  /* collision kernel only: this history's Threefry key schedule (see ThreefryKey) */
-  ThreefryKey key;
   unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
   unsigned nevents; /* events of this history so far: watchdog only */
@@ -521,7 +519,7 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables, bool kKeptKey = false, typename IndexPtr, typename Tally>
+template <bool kSameTables, typename IndexPtr, typename Tally>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
                                         const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
@@ -533,11 +531,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   const double p_absorb = kSameTables ? half_or_quotient(h.macro_a, h.macro_s + h.macro_a)
                                       : h.macro_a / (h.macro_s + h.macro_a);
   double rc0, rc1;
-  if (kKeptKey) {
-    generate_random_numbers(h.key, a.master_key, h.counter++, rc0, rc1);
-  } else {
-    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
-  }
+  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
 
   const bool absorbed = (rc0 < p_absorb);
   if (absorbed) {
@@ -576,11 +570,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   /* the draw for the next free flight (:293-295) needs nothing from the tables: it
    * and its logarithm are worked out while the search is still in flight */
   double rn0, rn1;
-  if (kKeptKey) {
-    generate_random_numbers(h.key, a.master_key, h.counter++, rn0, rn1);
-  } else {
-    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  }
+  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
   const double minus_log_rn0 = -log_of_sample(rn0);
 
   lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);

@@ -388,7 +388,6 @@ void history_regroup_kernel(SolveArgs a) {
         const unsigned e = *ring_slot(ring_head + rank);
         pid = (int)(e & ~kRequeued);
         load_record(h, a, a.rec[pid]);
-        h.key = threefry_key(a.pid_base + (uint64_t)h.id, a.master_key);
         resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
         if (e & kRequeued) {
           const SuspendExtra x = a.susp[pid];
@@ -430,7 +429,6 @@ void history_regroup_kernel(SolveArgs a) {
           if (take) {
             pid = (int)a.queue[mine];
             load_record(h, a, a.rec[pid]);
-        h.key = threefry_key(a.pid_base + (uint64_t)h.id, a.master_key);
             resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
           }
         } else if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
@@ -457,7 +455,7 @@ void history_regroup_kernel(SolveArgs a) {
         w_collide_passes++;
         if (want == kWantCollide) {
           ncollisions++;
-          if (collide<kSameTables, kQueue>(h, a, ix, tally)) {
+          if (collide<kSameTables>(h, a, ix, tally)) {
             put_back<kQueue>(h, a, pid);
             want = kWantRefill;
           } else {
