@@ -35,7 +35,7 @@ constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
  * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  K2
- * needs ~155 without spilling.  Both instantiations run at 3: the kernel is bound
+ * needs ~165 without spilling.  Both instantiations run at 3: the kernel is bound
  * by vector issue, and at 4 waves the spills (96 B of scratch since the state kept
  * per history grew) cost variant 1 6-20 % (profiles/r01g/baseline_configs.log;
  * the collision stage ran exactly as fast at 4 as at 3 when it spilled 56 B). */
