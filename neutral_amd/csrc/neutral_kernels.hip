@@ -311,6 +311,16 @@ void history_regroup_kernel(SolveArgs a) {
       decide(h, a);
     }
   };
+  /* after a collision in the collision stage: the event watchdog is applied once per
+   * run of back-to-back passes (below), not per collision */
+  auto next_event_after_collision = [&]() {
+    if (kQueue) {
+      decide<false>(h, a, edges);
+    } else {
+      decide(h, a);
+    }
+  };
+  unsigned long long w_ncollisions = 0; /* wave-level count (scalar) in the collision stage */
 
   /* wave-private slice of the particle queue (wave-uniform values) */
   int cur = 0;
@@ -451,15 +461,20 @@ void history_regroup_kernel(SolveArgs a) {
        * time slice ends, the passes follow each other without the three ballots
        * and the pass choice above. */
       bool slice_ends = false;
+      const bool collides_here = (want == kWantCollide);
+      unsigned inner = 0; /* passes of this run: every lane of m_collide executes all of them */
       for (;;) {
         w_collide_passes++;
+        inner++;
         if (want == kWantCollide) {
-          ncollisions++;
+          if (!kQueue) {
+            ncollisions++;
+          }
           if (collide<kSameTables>(h, a, ix, tally)) {
             put_back<kQueue>(h, a, pid);
             want = kWantRefill;
           } else {
-            next_event(false);
+            next_event_after_collision();
             want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
           }
         }
@@ -467,6 +482,17 @@ void history_regroup_kernel(SolveArgs a) {
                      (kSliceWindow == 0 || ring_count <= kSliceWindow);
         if (!kQueue || slice_ends || __ballot(want == kWantCollide) != m_collide) {
           break;
+        }
+      }
+      if (kQueue) {
+        w_ncollisions += (unsigned long long)inner * (unsigned)n_collide;
+        if (collides_here) {
+          h.nevents += inner;
+          if (h.nevents > kMaxEventsPerHistory && want != kWantRefill) {
+            atomicAdd(&a.counters->aborted, 1u);
+            h.ev = kEvEnd; /* ended like a history whose time has run out */
+            want = kWantStream;
+          }
         }
       }
       if (slice_ends) {
@@ -516,6 +542,7 @@ void history_regroup_kernel(SolveArgs a) {
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
   if ((threadIdx.x & 63) == 0) {
+    if (w_ncollisions) atomicAdd(&a.counters->ncollisions, w_ncollisions);
     if (w_requeued) atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
     if (w_collide_passes) {
       atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
