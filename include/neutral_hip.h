@@ -173,6 +173,11 @@ typedef struct {
   uint64_t collide_passes; /* wave-level collision passes of the event-regrouped kernel
                            (variants 1, 2): collisions / (64 * collide_passes) is the
                            lane occupancy of its collision passes */
+  int host_syncs;       /* times the call waited for the device (1 for a steady-state
+                           step of the tiled variant: the read-back of the counters) */
+  int stream_passes_enqueued; /* tiled variant: stream passes enqueued (the last step's
+                           count plus one when nothing was waited for in between) */
+  int tile_cells;       /* tiled variant: tile edge chosen for the problem (16..128 cells) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */
@@ -208,15 +213,29 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
                                     const double* edgey,
                                     const double initial_energy,
                                     NeutralHipParticle* particles);
-/* The tiled variant keeps the particles in a private array of records sorted by
- * mesh tile and, by default, writes them back to the SoA arrays of `particles`
- * at the end of every solve_transport_2d (a random scatter of 76 B/particle).
- * lazy != 0 defers that write-back until neutral_hip_sync_particles() (or a
- * call that needs the SoA arrays: another variant, reinject, free): use it
- * when nothing reads the arrays between timesteps, as main.c with
- * visit_dump = 0 (main.c:91-94,149-152). */
+/* Particle state and the tiled variant.  The tiled variant works on a private
+ * array of records sorted by mesh tile that MIRRORS the SoA store of `particles`.
+ * By default every kernel that ends a history also writes its final state to the
+ * SoA arrays (eleven scattered stores per particle and timestep), so the arrays are
+ * current whenever solve_transport_2d returns, as the reference's are.  In the other
+ * direction the arrays are read when the store is first stepped and after anything
+ * the library can see rewriting them: inject/reinject, and writes through its own
+ * hooks (copy_buffer, copy_int_buffer, neutral_hip_memcpy_h2d, neutral_hip_memset)
+ * that land inside the store.  A caller that changes particle arrays BEHIND the
+ * library's back (its own kernels, hipMemcpy) must say so with
+ * neutral_hip_invalidate_particles() before the next solve_transport_2d; the next
+ * step then re-imports the arrays (one pass over the store).
+ * lazy != 0 drops the per-history stores: the arrays are written back only by
+ * neutral_hip_sync_particles() (or a call that needs them: another variant, reinject,
+ * a read through the hooks, free): use it when nothing reads the arrays between
+ * timesteps, as main.c with visit_dump = 0 (main.c:91-94,149-152).
+ * Memory: the tally, density, edge and table arrays handed to solve_transport_2d must
+ * be ordinary (coarse-grained) device memory, e.g. from hipMalloc or the hooks above:
+ * the tally is accumulated with hardware f64 atomics (-munsafe-fp-atomics), which do
+ * nothing on fine-grained or host-mapped memory. */
 void neutral_hip_set_lazy_export(int lazy);
 void neutral_hip_sync_particles(NeutralHipParticle* particles);
+void neutral_hip_invalidate_particles(NeutralHipParticle* particles);
 /* Frees a store created by inject_particles. */
 void neutral_hip_free_particles(NeutralHipParticle* particles);
 /* Raw copies for callers without a HIP runtime of their own (ctypes, C). */

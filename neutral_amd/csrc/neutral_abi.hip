@@ -22,7 +22,8 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 3 /* 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log */
+#define NEUTRAL_ABI_VERSION 4 /* 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+                                 4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
 #define NEUTRAL_VALIDATE_TOLERANCE 1.0e-3 /* neutral_data.h:27 */
@@ -48,6 +49,27 @@ constexpr int kMaxIndexBuckets = 16384; /* u16 entries: 32 KB of LDS at most */
  * window to bisect shrinks from 4.5 to 2.8 keys on average, from 28 to 16 at most) */
 constexpr int kMaxFineIndexBuckets = 24576;
 
+/* What the library derives from the two cs tables and keeps from step to step: are
+ * they the same data (one search per energy), and the bucketed indexes over their
+ * keys.  Keyed by the table pointers and sizes; the CONTENTS are re-checked on the
+ * device every step (tables_check_kernel), so rewriting a table in place is noticed. */
+struct TableView {
+  bool valid = false;
+  const double* keys_s = nullptr;
+  const double* values_s = nullptr;
+  int n_s = 0;
+  const double* keys_a = nullptr;
+  const double* values_a = nullptr;
+  int n_a = 0;
+  int variant = -1;
+  unsigned long long hash_s = 0;
+  unsigned long long hash_a = 0;
+  int same = 0;
+  neutral::CsIndex ix_s = {nullptr, 0, 0, 0};
+  neutral::CsIndex ix_a = {nullptr, 0, 0, 0};
+  neutral::CsIndex fine = {nullptr, 0, 0, 0};
+};
+
 struct State {
   hipStream_t stream = nullptr;
   uint64_t pid_base = 0;
@@ -60,6 +82,7 @@ struct State {
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
   int* d_flag = nullptr;
+  unsigned long long* d_check = nullptr;            /* 4 words of tables_check_kernel */
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   unsigned short* d_index_fine = nullptr;           /* finer index of the collision stage */
   hipEvent_t ev_start = nullptr;
@@ -67,6 +90,7 @@ struct State {
   hipEvent_t ev_sorted = nullptr;   /* tiled variant: after the sort */
   hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   hipEvent_t ev_collected = nullptr; /* tiled variant: after the collision queue is built */
+  TableView tables;
   /* workspace of the tiled variant, grown on demand */
   neutral::TiledArgs tiled = {};
   /* which particle store the records mirror, and which copy is current */
@@ -76,7 +100,11 @@ struct State {
   bool rec_valid = false;          /* records hold the current state */
   bool soa_valid = true;           /* SoA arrays hold the current state */
   int lazy_export = 0;
-  int last_passes = 0;
+  /* what the last step of this record store needed: the next step is enqueued on that
+   * assumption, without waiting for the device in between (0 / -1: nothing known) */
+  int plan_passes = 0;
+  long long plan_queue = -1;
+  int host_syncs = 0;              /* waits for the device inside the current call */
   /* mesh extent: only for the tiled variant's "facets still ahead" estimate */
   double mesh_width = 1.0;
   double mesh_height = 1.0;
@@ -99,6 +127,8 @@ void ensure_scratch() {
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
   HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
   HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
+  HIP_CHECK(hipMalloc((void**)&g.d_check, 4 * sizeof(unsigned long long)));
+  g.tables.valid = false; /* its indexes live in the other device's scratch */
   HIP_CHECK(hipMalloc((void**)&g.d_index_fine,
                       sizeof(unsigned short) * (kMaxFineIndexBuckets + 1)));
   for (unsigned short*& d : g.d_index) {
@@ -129,6 +159,12 @@ void read_variant_env() {
   }
 }
 
+/* every wait for the device goes through here: NeutralHipStepStats.host_syncs */
+void wait_for_stream() {
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  g.host_syncs++;
+}
+
 void* device_zalloc(size_t bytes) {
   void* p = nullptr;
   HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
@@ -152,7 +188,7 @@ neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_star
   HIP_CHECK(hipMemcpyAsync(&ends[0], d_keys, sizeof(double), hipMemcpyDeviceToHost, g.stream));
   HIP_CHECK(hipMemcpyAsync(&ends[1], d_keys + (n - 1), sizeof(double), hipMemcpyDeviceToHost,
                            g.stream));
-  HIP_CHECK(hipStreamSynchronize(g.stream));
+  wait_for_stream();
   if (!(ends[0] > 0.0) || !(ends[1] > ends[0])) {
     return ix;
   }
@@ -172,49 +208,6 @@ neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_star
   return ix;
 }
 
-/* (Re)allocates the tiled variant's workspace for this problem size. */
-void ensure_tiled_workspace(int nx, int ny, int nparticles) {
-  int tx, ty, max_chunks;
-  neutral::tiled_geometry(nx, ny, nparticles, &tx, &ty, &max_chunks);
-  neutral::TiledArgs& t = g.tiled;
-  if (nparticles > g.tiled_particles || tx * ty > g.tiled_tiles) {
-    void* old[] = {t.order,     t.collide_queue, t.keys_in, t.keys_out, t.sort_temp,
-                   t.tile_offset, t.rec_in,      t.rec_out, t.info_in,  t.info_out,
-                   t.susp};
-    g.rec_valid = false;
-    for (void* p : old) {
-      if (p) HIP_CHECK(hipFree(p));
-    }
-    const size_t n = (size_t)nparticles;
-    HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.keys_in, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.keys_out, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
-    HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
-    HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
-    t.sort_temp_bytes = neutral::tiled_sort_temp_bytes(nparticles, tx * ty);
-    HIP_CHECK(hipMalloc(&t.sort_temp, t.sort_temp_bytes ? t.sort_temp_bytes : 16));
-    HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * (size_t)(tx * ty + 2)));
-    g.tiled_particles = nparticles;
-    g.tiled_tiles = tx * ty;
-  }
-  if (max_chunks > g.tiled_chunks) {
-    if (t.chunks) HIP_CHECK(hipFree(t.chunks));
-    HIP_CHECK(hipMalloc((void**)&t.chunks, sizeof(uint4) * (size_t)max_chunks));
-    g.tiled_chunks = max_chunks;
-  }
-  if (!t.ctrl) {
-    HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 8));
-  }
-  t.tiles_x = tx;
-  t.tiles_y = ty;
-  t.ntiles = tx * ty;
-  t.max_chunks = max_chunks;
-}
-
 /* Writes the records back to the SoA store they mirror if they are ahead of it.
  * Safe to call with any (or no) store in hand: the owner's arrays are remembered. */
 void sync_soa() {
@@ -222,9 +215,166 @@ void sync_soa() {
     /* order[] is free between solves: scratch for the inverse permutation */
     HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.order, g.rec_owner_view,
                                              g.rec_count, g.stream));
-    HIP_CHECK(hipStreamSynchronize(g.stream));
+    wait_for_stream();
   }
   g.soa_valid = true;
+}
+
+/* The records no longer mirror their SoA store (it was rewritten, or the record
+ * layout changes): the next tiled step imports it again. */
+void drop_records() {
+  g.rec_valid = false;
+  g.plan_passes = 0;
+  g.plan_queue = -1;
+}
+
+/* (Re)allocates the tiled variant's workspace for this problem size. */
+void ensure_tiled_workspace(int nx, int ny, int nparticles) {
+  int tx, ty, max_chunks;
+  const int shift = neutral::tiled_tile_shift(nx, ny, nparticles);
+  neutral::tiled_geometry(nx, ny, nparticles, shift, &tx, &ty, &max_chunks);
+  neutral::TiledArgs& t = g.tiled;
+  const bool grow = nparticles > g.tiled_particles || tx * ty > g.tiled_tiles;
+  if (grow || shift != t.tile_shift || tx != t.tiles_x || ty != t.tiles_y) {
+    /* the record summaries hold tile numbers of the old geometry, and the buffers
+     * may be about to go: a pending write-back of their owner comes first */
+    sync_soa();
+    drop_records();
+  }
+  if (grow) {
+    void* old[] = {t.order,   t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor,
+                   t.rec_in,  t.rec_out,       t.info_in,    t.info_out,    t.susp};
+    for (void* p : old) {
+      if (p) HIP_CHECK(hipFree(p));
+    }
+    const size_t n = (size_t)nparticles;
+    const size_t nb = (size_t)(tx * ty + 2);
+    HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
+    HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
+    HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
+    HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
+    HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));
+    HIP_CHECK(hipMalloc((void**)&t.tile_cursor, sizeof(unsigned) * nb));
+    g.tiled_particles = nparticles;
+    g.tiled_tiles = tx * ty;
+  }
+  /* the counting sort expects its histogram zeroed (it clears what it consumes) */
+  HIP_CHECK(hipMemsetAsync(t.tile_count, 0, sizeof(unsigned) * (size_t)(tx * ty + 2), g.stream));
+  if (max_chunks > g.tiled_chunks) {
+    if (t.chunks) HIP_CHECK(hipFree(t.chunks));
+    HIP_CHECK(hipMalloc((void**)&t.chunks, sizeof(uint4) * (size_t)max_chunks));
+    g.tiled_chunks = max_chunks;
+  }
+  if (!t.ctrl) {
+    HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 8));
+    HIP_CHECK(hipMemsetAsync(t.ctrl, 0, sizeof(unsigned) * 8, g.stream));
+  }
+  t.tile_shift = shift;
+  t.window_min_particles = neutral::tiled_window_min_particles(shift);
+  t.tiles_x = tx;
+  t.tiles_y = ty;
+  t.ntiles = tx * ty;
+  t.max_chunks = max_chunks;
+}
+
+/* true when [p, p + bytes) overlaps one of the arrays of the store the records mirror */
+bool touches_record_owner(const void* p, size_t bytes) {
+  if (!g.rec_owner || !g.rec_valid) {
+    return false;
+  }
+  const neutral::ParticleView& v = g.rec_owner_view;
+  const size_t n = (size_t)g.rec_count;
+  const char* lo = (const char*)p;
+  const char* hi = lo + bytes;
+  const void* f64[] = {v.x, v.y, v.omega_x, v.omega_y, v.energy, v.weight, v.dt_to_census,
+                       v.mfp_to_collision};
+  for (const void* a : f64) {
+    if (lo < (const char*)a + sizeof(double) * n && hi > (const char*)a) return true;
+  }
+  const void* i32[] = {v.cellx, v.celly, v.dead};
+  for (const void* a : i32) {
+    if (lo < (const char*)a + sizeof(int) * n && hi > (const char*)a) return true;
+  }
+  return false;
+}
+
+/* a caller is about to overwrite device memory through one of the library's own
+ * copy hooks: if it is part of the mirrored particle store, the store becomes the
+ * truth again (pending record state is written back first, so a partial overwrite
+ * keeps the rest) */
+void before_device_write(const void* dst, size_t bytes) {
+  if (touches_record_owner(dst, bytes)) {
+    sync_soa();
+    drop_records();
+  }
+}
+
+/* What the library derives from the cs tables (see TableView).  Builds the view when
+ * the tables (pointers, sizes, variant) are new -- that waits for the device -- and
+ * otherwise only enqueues the device-side check of the contents. */
+void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCrossSection* cs_a,
+                        bool rebuild) {
+  TableView& v = g.tables;
+  const bool same_args = v.valid && v.keys_s == cs_s->keys && v.values_s == cs_s->values &&
+                         v.n_s == cs_s->nentries && v.keys_a == cs_a->keys &&
+                         v.values_a == cs_a->values && v.n_a == cs_a->nentries &&
+                         v.variant == g.variant;
+  if (!same_args || rebuild) {
+    v.valid = false;
+    v.keys_s = cs_s->keys;
+    v.values_s = cs_s->values;
+    v.n_s = cs_s->nentries;
+    v.keys_a = cs_a->keys;
+    v.values_a = cs_a->values;
+    v.n_a = cs_a->nentries;
+    v.variant = g.variant;
+    /* identity and key hashes from the check kernel itself (expectations unknown) */
+    HIP_CHECK(neutral::launch_tables_check(v.keys_s, v.values_s, v.n_s, v.keys_a, v.values_a, v.n_a,
+                                           0ull, 0ull, -1, g.d_check, g.stream));
+    unsigned long long h[4];
+    HIP_CHECK(hipMemcpyAsync(h, g.d_check, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    wait_for_stream();
+    v.hash_s = h[1];
+    v.hash_a = h[2];
+    v.same = (int)h[3];
+    /* bucketed indexes */
+    v.ix_s = build_index(v.keys_s, v.n_s, g.d_index[0]);
+    v.ix_a = v.ix_s;
+    if (!v.same) {
+      v.ix_a = build_index(v.keys_a, v.n_a, g.d_index[1]);
+      if (v.ix_a.start && v.ix_s.start && v.ix_a.shift != v.ix_s.shift) {
+        v.ix_a.start = nullptr; /* one shift per launch: the absorb table falls back to bisection */
+      }
+      if (!v.ix_s.start && v.ix_a.start) {
+        v.ix_s.shift = v.ix_a.shift;
+      }
+    }
+    v.fine = {nullptr, 0, 0, 0};
+    if (v.same && v.ix_s.start && g.variant == NEUTRAL_HIP_VARIANT_TILED) {
+      const neutral::CsIndex fine =
+          build_index(v.keys_s, v.n_s, g.d_index_fine, 43, kMaxFineIndexBuckets);
+      if (fine.start && fine.shift < v.ix_s.shift) {
+        v.fine = fine;
+      }
+    }
+    v.valid = true;
+  }
+  /* every step: the contents against the view (result read with the step's counters) */
+  HIP_CHECK(neutral::launch_tables_check(v.keys_s, v.values_s, v.n_s, v.keys_a, v.values_a, v.n_a,
+                                         v.hash_s, v.hash_a, v.same, g.d_check, g.stream));
+}
+
+int device_cus() {
+  int dev = 0;
+  int cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  return cus;
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -266,7 +416,7 @@ void run_inject(const int nparticles, const int local_nx, const int local_ny, co
   a.edgey = edgey;
   a.p = view_of(particles);
   if (g.rec_owner == (const void*)particles->x) {
-    g.rec_valid = false; /* the SoA store is about to be rewritten */
+    drop_records(); /* the SoA store is about to be rewritten */
     g.soa_valid = true;
   }
   HIP_CHECK(neutral::launch_inject(a, g.stream));
@@ -314,24 +464,11 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
 
   read_variant_env();
   ensure_scratch();
-
-  /* Identical tables (the shipped elastic_scatter.cs / capture.cs are) need one
-   * search per energy instead of two.  Decided from the data on every call, so
-   * a caller that rewrites a table in place is still served correctly. */
-  int same = 0;
-  if (cs_scatter_table->nentries == cs_absorb_table->nentries) {
-    if (cs_scatter_table->keys == cs_absorb_table->keys &&
-        cs_scatter_table->values == cs_absorb_table->values) {
-      same = 1;
-    } else {
-      int one = 1;
-      HIP_CHECK(hipMemcpyAsync(g.d_flag, &one, sizeof(int), hipMemcpyHostToDevice, g.stream));
-      HIP_CHECK(neutral::launch_tables_equal(cs_scatter_table->keys, cs_scatter_table->values,
-                                             cs_absorb_table->keys, cs_absorb_table->values,
-                                             cs_scatter_table->nentries, g.d_flag, g.stream));
-      HIP_CHECK(hipMemcpyAsync(&same, g.d_flag, sizeof(int), hipMemcpyDeviceToHost, g.stream));
-      HIP_CHECK(hipStreamSynchronize(g.stream));
-    }
+  g.host_syncs = 0;
+  const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
+  if (tiled && pad != 0) {
+    fprintf(stderr, "libneutral_hip: the tiled variant needs pad = 0 (as main.c:33 sets).\n");
+    exit(EXIT_FAILURE);
   }
 
   neutral::SolveArgs a;
@@ -351,44 +488,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.density = density;
   a.edgex = edgex;
   a.edgey = edgey;
-  a.scatter_keys = cs_scatter_table->keys;
-  a.scatter_values = cs_scatter_table->values;
-  a.scatter_n = cs_scatter_table->nentries;
-  a.absorb_keys = cs_absorb_table->keys;
-  a.absorb_values = cs_absorb_table->values;
-  a.absorb_n = cs_absorb_table->nentries;
-  a.same_tables = same;
-  /* bucketed indexes, rebuilt per call like the equality test (tables may change) */
-  neutral::CsIndex ix_s = build_index(cs_scatter_table->keys, cs_scatter_table->nentries,
-                                      g.d_index[0]);
-  neutral::CsIndex ix_a = ix_s;
-  if (!same) {
-    ix_a = build_index(cs_absorb_table->keys, cs_absorb_table->nentries, g.d_index[1]);
-    if (ix_a.start && ix_s.start && ix_a.shift != ix_s.shift) {
-      ix_a.start = nullptr; /* one shift per launch: the absorb table falls back to bisection */
-    }
-    if (!ix_s.start && ix_a.start) {
-      ix_s.shift = ix_a.shift;
-    }
-  }
-  a.scatter_index = ix_s.start;
-  a.scatter_index_n = ix_s.nbuckets;
-  a.scatter_index_base = ix_s.base;
-  a.absorb_index = ix_a.start;
-  a.absorb_index_n = ix_a.nbuckets;
-  a.absorb_index_base = ix_a.base;
-  a.index_shift = ix_s.start ? ix_s.shift : ix_a.shift;
-  g.tiled.fine_index = nullptr;
-  if (same && ix_s.start && g.variant == NEUTRAL_HIP_VARIANT_TILED) {
-    const neutral::CsIndex fine = build_index(cs_scatter_table->keys, cs_scatter_table->nentries,
-                                              g.d_index_fine, 43, kMaxFineIndexBuckets);
-    if (fine.start && fine.shift < ix_s.shift) {
-      g.tiled.fine_index = fine.start;
-      g.tiled.fine_index_n = fine.nbuckets;
-      g.tiled.fine_index_base = fine.base;
-      g.tiled.fine_index_shift = fine.shift;
-    }
-  }
   a.tally = energy_deposition_tally;
   a.counters = g.d_counters;
   a.queue = nullptr;
@@ -398,47 +497,26 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.max_blocks = 0;
   a.slot_info = nullptr;
   a.tiles_x = 0;
+  a.tile_shift = 4;
   a.susp = nullptr;
+  a.export_soa = (tiled && !g.lazy_export) ? 1 : 0;
+  a.abort_flag = (const int*)g.d_check; /* low word of tables_check_kernel's verdict */
 
-  HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
-  const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
   if (tiled) {
-    if (pad != 0) {
-      fprintf(stderr, "libneutral_hip: the tiled variant needs pad = 0 (as main.c:33 sets).\n");
-      exit(EXIT_FAILURE);
-    }
     ensure_tiled_workspace(nx, ny, a.nparticles);
-    /* the tally window takes 128 KB of the 160 KB of LDS: an index that does
-     * not fit next to it stays in HBM-side bisection (same brackets) */
-    const size_t lds_limit = 160 * 1024 - 64;
-    if (neutral::tiled_lds_bytes(a) > lds_limit) {
-      a.absorb_index = nullptr;
-    }
-    if (neutral::tiled_lds_bytes(a) > lds_limit) {
-      a.scatter_index = nullptr;
-    }
-  }
-  if (tiled) {
     /* the records mirror one SoA store: (re)import when they are not current */
     if (!g.rec_valid || g.rec_owner != (const void*)particles->x ||
         g.rec_count != a.nparticles) {
       sync_soa(); /* a previous owner's pending write-back */
+      drop_records();
       HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
-                                               g.tiled.tiles_x, x_off, y_off, a.nparticles,
-                                               g.stream));
+                                               g.tiled.tiles_x, g.tiled.tile_shift, x_off, y_off,
+                                               a.nparticles, g.stream));
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
       g.rec_count = a.nparticles;
       g.rec_valid = true;
     }
-  } else {
-    sync_soa(); /* K1/K2 work on the SoA store in place */
-    if (g.rec_owner == (const void*)particles->x) {
-      g.rec_valid = false;
-    }
-  }
-  HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
-  if (tiled) {
     if (g.extent_edges != (const void*)edgex || g.extent_nx != nx || g.extent_ny != ny) {
       /* mesh extent from the edge arrays (four doubles, once per mesh) */
       double e[4];
@@ -448,7 +526,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(hipMemcpyAsync(&e[2], edgey + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
       HIP_CHECK(hipMemcpyAsync(&e[3], edgey + pad + ny, sizeof(double), hipMemcpyDeviceToHost,
                                g.stream));
-      HIP_CHECK(hipStreamSynchronize(g.stream));
+      wait_for_stream();
       g.mesh_width = (e[1] > e[0]) ? e[1] - e[0] : 1.0;
       g.mesh_height = (e[3] > e[2]) ? e[3] - e[2] : 1.0;
       g.extent_edges = (const void*)edgex;
@@ -457,28 +535,129 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
     g.tiled.cells_per_x = (double)nx / g.mesh_width;
     g.tiled.cells_per_y = (double)ny / g.mesh_height;
-    HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, g.ev_sorted, g.ev_streamed,
-                                          g.ev_collected, &g.last_passes));
   } else {
-    HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
-  }
-  HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
-  if (tiled) {
-    /* g.tiled.rec_in now holds this step's records, in tile order */
-    g.soa_valid = false;
-    if (!g.lazy_export) {
-      sync_soa();
+    sync_soa(); /* K1/K2 work on the SoA store in place */
+    if (g.rec_owner == (const void*)particles->x) {
+      drop_records();
     }
   }
 
   neutral::StepCounters hc[2];
-  HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
-  unsigned queue_len = 0;
-  if (tiled) {
-    HIP_CHECK(hipMemcpyAsync(&queue_len, &g.tiled.ctrl[2], sizeof(unsigned),
-                             hipMemcpyDeviceToHost, g.stream));
+  unsigned ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int passes = 0;
+  int same = 0;
+  for (int attempt = 0;; ++attempt) {
+    /* Identical tables (the shipped elastic_scatter.cs / capture.cs are) need one
+     * search per energy instead of two, and both searches start from a bucketed
+     * index.  The view is cached and its validity checked on the device (see
+     * TableView): when the check fails the kernels of this attempt have done
+     * nothing, and the step runs again with a fresh view. */
+    refresh_table_view(cs_scatter_table, cs_absorb_table, attempt > 0);
+    const TableView& v = g.tables;
+    same = v.same;
+    a.scatter_keys = cs_scatter_table->keys;
+    a.scatter_values = cs_scatter_table->values;
+    a.scatter_n = cs_scatter_table->nentries;
+    a.absorb_keys = cs_absorb_table->keys;
+    a.absorb_values = cs_absorb_table->values;
+    a.absorb_n = cs_absorb_table->nentries;
+    a.same_tables = same;
+    a.scatter_index = v.ix_s.start;
+    a.scatter_index_n = v.ix_s.nbuckets;
+    a.scatter_index_base = v.ix_s.base;
+    a.absorb_index = v.ix_a.start;
+    a.absorb_index_n = v.ix_a.nbuckets;
+    a.absorb_index_base = v.ix_a.base;
+    a.index_shift = v.ix_s.start ? v.ix_s.shift : v.ix_a.shift;
+    g.tiled.fine_index = nullptr;
+    if (tiled && v.fine.start) {
+      g.tiled.fine_index = v.fine.start;
+      g.tiled.fine_index_n = v.fine.nbuckets;
+      g.tiled.fine_index_base = v.fine.base;
+      g.tiled.fine_index_shift = v.fine.shift;
+    }
+    if (tiled) {
+      /* the tally window takes 128 KB of the 160 KB of LDS: an index that does
+       * not fit next to it stays in HBM-side bisection (same brackets) */
+      const size_t lds_limit = 160 * 1024 - 64;
+      if (neutral::tiled_lds_bytes(a) > lds_limit) {
+        a.absorb_index = nullptr;
+      }
+      if (neutral::tiled_lds_bytes(a) > lds_limit) {
+        a.scatter_index = nullptr;
+      }
+    }
+
+    HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
+    HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
+    if (tiled) {
+      neutral::TiledPlan plan;
+      plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 0;
+      plan.blocks_per_cu =
+          g.plan_queue >= 0
+              ? neutral::tiled_collision_blocks_per_cu((unsigned)g.plan_queue, device_cus())
+              : -1;
+      HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, plan, 0, g.ev_sorted,
+                                            g.ev_streamed, g.ev_collected, &passes,
+                                            &g.host_syncs));
+    } else {
+      HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
+    }
+    HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+
+    /* the one wait of a steady-state step: counters, the pipeline's control words
+     * and the verdict on the table view */
+    unsigned long long check[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
+    HIP_CHECK(hipMemcpyAsync(check, g.d_check, sizeof(check), hipMemcpyDeviceToHost, g.stream));
+    if (tiled) {
+      HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
+    }
+    wait_for_stream();
+    if (check[0] == 0) {
+      break;
+    }
+    if (attempt >= 2) {
+      fprintf(stderr, "libneutral_hip: the cross-section tables keep changing under "
+                      "solve_transport_2d.\n");
+      exit(EXIT_FAILURE);
+    }
   }
-  HIP_CHECK(hipStreamSynchronize(g.stream));
+
+  unsigned long long queue_total = ctrl[2];
+  if (tiled) {
+    /* migrants left over: the step outran the plan (it needs more stream passes than
+     * the last one did).  Finish it pass by pass; the newly suspended histories get
+     * a collision stage of their own (the first one's are marked done). */
+    while (ctrl[4] != 0) {
+      neutral::TiledPlan more = {0, -1};
+      HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
+                                            g.ev_streamed, g.ev_collected, &passes,
+                                            &g.host_syncs));
+      HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+      neutral::StepCounters again[2];
+      HIP_CHECK(hipMemcpyAsync(again, g.d_counters, sizeof(again), hipMemcpyDeviceToHost,
+                               g.stream));
+      HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
+      wait_for_stream();
+      hc[0] = again[0];
+      hc[1] = again[1];
+      queue_total += ctrl[2];
+    }
+    /* this step's records become the next step's input */
+    neutral::TiledArgs& t = g.tiled;
+    neutral::ParticleRec* swap = t.rec_in;
+    t.rec_in = t.rec_out;
+    t.rec_out = swap;
+    unsigned* swap_info = t.info_in;
+    t.info_in = t.info_out;
+    t.info_out = swap_info;
+    g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
+    g.plan_queue = (long long)queue_total;
+    /* eager mode: the kernels that ended a history wrote it to the SoA store */
+    g.soa_valid = a.export_soa ? true : false;
+  }
+
   float ms = 0.0f;
   HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
   float ms_sort = 0.0f, ms_stream = 0.0f, ms_collide = ms;
@@ -513,15 +692,18 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.collide_ms = (double)ms_collide;
   g.last.stream_facets = tiled ? hc[0].nfacets : 0;
   g.last.stream_census = tiled ? hc[0].ncensus : 0;
-  g.last.suspended = queue_len;
+  g.last.suspended = queue_total;
   g.last.aborted = (uint64_t)hc[0].aborted + (uint64_t)hc[1].aborted;
   if (g.last.aborted) {
     fprintf(stderr, "libneutral_hip: warning: %llu histories exceeded the event watchdog and "
                     "were stopped.\n", (unsigned long long)g.last.aborted);
   }
-  g.last.stream_passes = tiled ? g.last_passes : 0;
+  g.last.stream_passes = tiled ? (int)ctrl[5] : 0;
   g.last.requeued = tiled ? hc[1].nrequeued : 0;
   g.last.collide_passes = hc[0].ncollide_passes + hc[1].ncollide_passes;
+  g.last.host_syncs = g.host_syncs;
+  g.last.stream_passes_enqueued = tiled ? passes : 0;
+  g.last.tile_cells = tiled ? (1 << g.tiled.tile_shift) : 0;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */
@@ -650,11 +832,21 @@ void deallocate_host_data(double* buf) { free(buf); }
 
 void copy_buffer(const size_t len, double** src, double** dst, int send) {
   const hipMemcpyKind kind = send ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  if (send) {
+    if (touches_record_owner(*src, sizeof(double) * len)) sync_soa(); /* lazy export pending */
+  } else {
+    before_device_write(*dst, sizeof(double) * len);
+  }
   HIP_CHECK(hipMemcpyAsync(*dst, *src, sizeof(double) * len, kind, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void copy_int_buffer(const size_t len, int** src, int** dst, int send) {
   const hipMemcpyKind kind = send ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  if (send) {
+    if (touches_record_owner(*src, sizeof(int) * len)) sync_soa(); /* lazy export pending */
+  } else {
+    before_device_write(*dst, sizeof(int) * len);
+  }
   HIP_CHECK(hipMemcpyAsync(*dst, *src, sizeof(int) * len, kind, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
@@ -724,13 +916,22 @@ void neutral_hip_sync_particles(NeutralHipParticle* particles) {
   sync_soa();
 }
 
+void neutral_hip_invalidate_particles(NeutralHipParticle* particles) {
+  if (particles && g.rec_owner == (const void*)particles->x) {
+    /* whatever the records hold that the arrays do not have yet goes out first, so
+     * a caller that changed SOME particles keeps the others */
+    sync_soa();
+    drop_records();
+  }
+}
+
 void neutral_hip_free_particles(NeutralHipParticle* p) {
   if (!p) {
     return;
   }
   if (g.rec_owner == (const void*)p->x) {
     g.rec_owner = nullptr; /* pending state dies with the store */
-    g.rec_valid = false;
+    drop_records();
     g.soa_valid = true;
   }
   void* arrays[] = {p->x,      p->y,           p->omega_x,          p->omega_y, p->energy,
@@ -745,14 +946,17 @@ void neutral_hip_free_particles(NeutralHipParticle* p) {
 }
 
 void neutral_hip_memcpy_d2h(void* dst_host, const void* src_device, size_t bytes) {
+  if (touches_record_owner(src_device, bytes)) sync_soa(); /* lazy export pending */
   HIP_CHECK(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void neutral_hip_memcpy_h2d(void* dst_device, const void* src_host, size_t bytes) {
+  before_device_write(dst_device, bytes);
   HIP_CHECK(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 void neutral_hip_memset(void* dst_device, int value, size_t bytes) {
+  before_device_write(dst_device, bytes);
   HIP_CHECK(hipMemsetAsync(dst_device, value, bytes, g.stream));
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }

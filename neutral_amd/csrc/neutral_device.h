@@ -1,8 +1,9 @@
 /*
  * neutral_device.h -- device-side building blocks of the MI355X (gfx950)
  * over-particle transport path: Threefry2x64-20, the (0,1] double conversion,
- * cross-section bracket search, distance-to-facet, the path-length heating
- * estimator and the three event bodies.
+ * cross-section bracket search, distance-to-facet and the division / square-root /
+ * logarithm forms of the event bodies (the bodies themselves, with the path-length
+ * heating estimator, are in neutral_history.h).
  *
  * What is computed follows the reference's omp3 kernel set (the parity oracle,
  * SURVEY.md section 2.3); each routine names the lines it answers to.  How it
@@ -344,23 +345,6 @@ __device__ __forceinline__ void calc_distance_to_facet(
   x_facet = (dt_x < dt_y) ? 1 : 0;
 
   distance_to_facet = x_facet ? (ax * speed) * u_x_inv : (ay * speed) * u_y_inv;
-}
-
-/* ---- heating estimator (omp3/neutral.c:474-495) ---------------------------- */
-
-__device__ __forceinline__ double calculate_energy_deposition(
-    double energy, double weight, double path_length, double number_density,
-    double microscopic_cs_absorb, double microscopic_cs_total) {
-  constexpr double average_exit_energy_absorb = 0.0;
-  const double absorption_heating =
-      (microscopic_cs_absorb / microscopic_cs_total) * average_exit_energy_absorb;
-  const double average_exit_energy_scatter =
-      energy * ((kMassNo * kMassNo + kMassNo + 1) / ((kMassNo + 1) * (kMassNo + 1)));
-  const double scattering_heating =
-      (1.0 - (microscopic_cs_absorb / microscopic_cs_total)) * average_exit_energy_scatter;
-  const double heating_response = (energy - scattering_heating - absorption_heating);
-  return weight * path_length * (microscopic_cs_total * kBarns) * heating_response *
-         number_density;
 }
 
 __device__ __forceinline__ double speed_of(double energy) {

@@ -381,15 +381,12 @@ enum RecState : int {
   kRecMigrate = 3,   /* left its tally window, waits for the next streaming pass */
 };
 
-#ifndef NEUTRAL_TILE_CELLS
-#define NEUTRAL_TILE_CELLS 16
-#endif
-constexpr int kTileCells = NEUTRAL_TILE_CELLS; /* cells per tile edge of the tiled variant */
-
-/* record summary: state in the top two bits, tile of the cell below */
-__device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x) {
+/* record summary: state in the top two bits, tile of the cell below (tiles of
+ * 1 << tile_shift cells per edge: the tiled variant picks 16..128 per problem) */
+__device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x,
+                                                 int tile_shift) {
   return ((unsigned)state << 30) |
-         (unsigned)((celly / kTileCells) * tiles_x + (cellx / kTileCells));
+         (unsigned)((celly >> tile_shift) * tiles_x + (cellx >> tile_shift));
 }
 
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,

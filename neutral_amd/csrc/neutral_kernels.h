@@ -124,25 +124,33 @@ struct SolveArgs {
   int max_blocks;            /* > 0: cap on the regroup kernel's grid (test knob) */
   unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
+  int tile_shift;            /* log2 of the tile edge in cells (4..7) */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
+  /* tiled variant: a history that ends also writes its final state to the SoA store
+   * `p` at its id, so the interface's arrays are current when solve_transport_2d
+   * returns (0: lazy export, the records are written back on demand) */
+  int export_soa;
+  /* [device] non-zero: the host's cached view of the cs tables (identity, bucketed
+   * indexes) no longer matches the tables; history kernels return at once and the
+   * host re-runs the step with a fresh view (null: no cached view in use) */
+  const int* abort_flag;
 };
 
 /* device workspace of the tiled pipeline (neutral_tiled.hip), owned by the ABI */
 struct TiledArgs {
-  ParticleRec* rec_in;     /* nparticles: records in last step's order */
-  ParticleRec* rec_out;    /* nparticles: records in this step's tile order */
+  ParticleRec* rec_in;     /* nparticles: last step's records (source of pass 0) */
+  ParticleRec* rec_out;    /* nparticles: this step's records, in this step's tile order */
   /* 4-B summary of each record, written with it: state << 30 | tile of its cell.
-   * The sort keys and the collision queue are built from these 4 bytes instead
+   * The counting sort and the collision queue are built from these 4 bytes instead
    * of a strided read of the 80-B records. */
   unsigned* info_in;
   unsigned* info_out;
-  unsigned* order;         /* nparticles: rec_in indices sorted by tile (dead ones last) */
-  unsigned* keys_in;       /* nparticles: tile of each particle, ntiles when dead */
-  unsigned* keys_out;      /* nparticles: sorted keys */
-  void* sort_temp;         /* rocPRIM radix sort scratch */
-  size_t sort_temp_bytes;
-  unsigned* tile_offset;   /* ntiles + 2: first sorted position of each key */
-  uint4* chunks;           /* max_chunks: {begin, end, tile, -} into order[] */
+  unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
+                              the dead last; later passes: the migrants, into rec_out) */
+  unsigned* tile_count;    /* ntiles + 2: histogram of the counting sort (zero between uses) */
+  unsigned* tile_offset;   /* ntiles + 2: first sorted position of each bucket */
+  unsigned* tile_cursor;   /* ntiles + 2: next free position of each bucket during placement */
+  uint4* chunks;           /* max_chunks: {begin, end, tile, windowed} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
   /* finer bucketed index for the collision stage (identical tables only; null: none) */
@@ -150,16 +158,27 @@ struct TiledArgs {
   int fine_index_n;
   long long fine_index_base;
   int fine_index_shift;
-  unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants */
+  unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants,
+                              passes used */
   int chunk_particles;     /* particles one workgroup takes at a time */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */
   int allow_migrate;       /* 0 on the last permitted pass: finish with global atomics */
   double cells_per_x;      /* nx / mesh width, ny / mesh height: for the estimate of how */
   double cells_per_y;      /* many facets a history still has to cross */
+  int tile_shift;          /* log2 of the tile edge in cells: 4 (16 cells) .. 7 (128) */
+  int window_min_particles; /* a chunk with fewer particles tallies straight to HBM */
   int tiles_x;
   int tiles_y;
   int ntiles;
   int max_chunks;
+};
+
+/* what the host knows before it enqueues a timestep of the tiled pipeline */
+struct TiledPlan {
+  int stream_passes; /* > 0: enqueue this many stream passes back to back (last step's
+                        count plus one); 0: look at the migrant counter after every pass */
+  int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit);
+                        < 0: read the queue length first (a host synchronisation) */
 };
 
 enum Variant {
@@ -173,26 +192,44 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
 /* *d_flag (device int) = 1 when the two tables are element-wise identical */
 hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
                                const double* vb, int n, int* d_flag, hipStream_t stream);
+/* The host's cached view of the two cs tables, re-checked on the device every step:
+ * out[0] = 1 unless hash(scatter keys) == expect_hash_s, hash(absorb keys) ==
+ * expect_hash_a and (tables element-wise identical) == expect_same; out[1], out[2] =
+ * the two hashes, out[3] = the identity flag (all four words are written). */
+hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
+                               const double* va, int na, unsigned long long expect_hash_s,
+                               unsigned long long expect_hash_a, int expect_same,
+                               unsigned long long* out4, hipStream_t stream);
 
 
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
 size_t tiled_lds_bytes(const SolveArgs& a);
-size_t tiled_sort_temp_bytes(int nparticles, int ntiles);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 int tiles_x, int x_off, int y_off, int n, hipStream_t stream);
+                                 int tiles_x, int tile_shift, int x_off, int y_off, int n,
+                                 hipStream_t stream);
 /* slot_of_id: nparticles words of scratch (the sort's order[] array serves) */
 hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream);
-void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks);
-/* a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
- * collision kernel.  The optional events are recorded after the first sort,
- * after the last streaming pass and after the collision queue is built.  Synchronises the stream once per pass (the
- * migrant count decides whether another pass runs).  On return t.rec_in holds
- * the records of this step (t.rec_in / t.rec_out are swapped per pass). */
+/* tile edge (log2 cells) and window threshold for a problem; tiles and chunk capacity */
+int tiled_tile_shift(int nx, int ny, int nparticles);
+int tiled_window_min_particles(int tile_shift);
+void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
+                    int* max_chunks);
+int tiled_collision_blocks_per_cu(unsigned queued, int cus);
+/* Enqueues stream passes first_pass.. (plan), the collision queue and the collision
+ * stage.  a.counters must point at TWO StepCounters records: [0] streaming kernel,
+ * [1] collision kernel.  The optional events are recorded after the first sort,
+ * after the last enqueued streaming pass and after the collision queue is built.
+ * With plan.stream_passes > 0 and plan.blocks_per_cu >= 0 nothing here waits for the
+ * device: the caller reads t.ctrl (migrants left over, passes used, queue length)
+ * with the step's counters and calls again with first_pass = *passes_enqueued if
+ * migrants are left.  This step's records are t.rec_out / t.info_out (the caller
+ * swaps in/out when the step is complete).  *host_syncs is incremented per wait. */
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream,
-                              hipEvent_t after_collect, int* npasses);
+                              const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
+                              hipEvent_t after_stream, hipEvent_t after_collect,
+                              int* passes_enqueued, int* host_syncs);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

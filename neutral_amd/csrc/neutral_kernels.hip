@@ -115,6 +115,9 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
 
+  if (a.abort_flag && *a.abort_flag) {
+    return; /* the cached view of the cs tables is stale: the host re-runs the step */
+  }
   if (pid < a.nparticles && !a.p.dead[pid]) { /* omp3/neutral.c:91-93 */
     nprocessed = 1;
     const CsLookup<const unsigned short*> ix{a.scatter_index, a.absorb_index};
@@ -243,7 +246,11 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
     store_record(h, a, a.rec[pid], state);
-    a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x);
+    a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
+                                    a.tile_shift);
+    if (a.export_soa) {
+      store_particle(h, a, (int)h.id); /* the interface's arrays stay current */
+    }
   } else {
     store_particle(h, a, pid);
   }
@@ -261,6 +268,9 @@ void history_regroup_kernel(SolveArgs a) {
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
 
+  if (a.abort_flag && *a.abort_flag) {
+    return; /* the cached view of the cs tables is stale: the host re-runs the step */
+  }
   /* stage the bucketed cs index(es) in LDS: nbuckets+1 u16 entries each */
   extern __shared__ unsigned short lds_index[];
   CsLookup<const unsigned short*> ix{nullptr, nullptr};
@@ -593,6 +603,79 @@ __global__ __launch_bounds__(kBlock) void tables_equal_kernel(const double* ka, 
   }
 }
 
+/* The host caches what it derived from the tables (identity, bucketed indexes) and
+ * this kernel re-checks the cache on the device every step, so a caller that rewrites
+ * a table in place is still served correctly without a host round trip per step: on a
+ * mismatch it raises out[0], the history kernels return at once, and the host
+ * rebuilds its view and runs the step again.  Single workgroup. */
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+__global__ __launch_bounds__(1024) void tables_check_kernel(
+    const double* ks, const double* vs, int ns, const double* ka, const double* va, int na,
+    unsigned long long expect_hash_s, unsigned long long expect_hash_a, int expect_same,
+    unsigned long long* out) {
+  __shared__ unsigned long long s_hs[16], s_ha[16];
+  __shared__ int s_diff[16];
+  unsigned long long hs = 0, ha = 0;
+  int diff = (ns != na) ? 1 : 0;
+  for (int i = threadIdx.x; i < ns; i += 1024) {
+    const unsigned long long k = (unsigned long long)__double_as_longlong(ks[i]);
+    hs += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
+  }
+  for (int i = threadIdx.x; i < na; i += 1024) {
+    const unsigned long long k = (unsigned long long)__double_as_longlong(ka[i]);
+    ha += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
+  }
+  if (ns == na) {
+    for (int i = threadIdx.x; i < ns; i += 1024) {
+      /* bit comparison: NaNs and signed zeros must not compare "equal enough" */
+      diff |= (__double_as_longlong(ks[i]) != __double_as_longlong(ka[i])) ||
+              (__double_as_longlong(vs[i]) != __double_as_longlong(va[i]));
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    hs += __shfl_down(hs, off, 64);
+    ha += __shfl_down(ha, off, 64);
+    diff |= __shfl_down(diff, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_hs[threadIdx.x >> 6] = hs;
+    s_ha[threadIdx.x >> 6] = ha;
+    s_diff[threadIdx.x >> 6] = diff;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hs = ha = 0;
+    diff = 0;
+    for (int w = 0; w < 16; ++w) {
+      hs += s_hs[w];
+      ha += s_ha[w];
+      diff |= s_diff[w];
+    }
+    const int same = diff ? 0 : 1;
+    out[1] = hs;
+    out[2] = ha;
+    out[3] = (unsigned long long)same;
+    out[0] = (hs != expect_hash_s || ha != expect_hash_a || same != expect_same) ? 1ull : 0ull;
+  }
+}
+
+hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
+                               const double* va, int na, unsigned long long expect_hash_s,
+                               unsigned long long expect_hash_a, int expect_same,
+                               unsigned long long* out4, hipStream_t stream) {
+  hipLaunchKernelGGL(tables_check_kernel, dim3(1), dim3(1024), 0, stream, ks, vs, ns, ka, va, na,
+                     expect_hash_s, expect_hash_a, expect_same, out4);
+  return hipGetLastError();
+}
+
 /* ---- probes: unit-level access to the device building blocks (for KATs) ----- */
 
 __global__ __launch_bounds__(kBlock) void probe_threefry_kernel(const uint64_t* in, uint64_t* out,
@@ -727,18 +810,19 @@ hipError_t launch_inject(const InjectArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-/* blocks of kBlock threads the device keeps resident for a kernel */
+/* blocks of kBlock threads the device keeps resident for a kernel that takes `lds`
+ * bytes of dynamic LDS per block */
 template <typename K>
-static int resident_blocks(K kernel) {
+static int resident_blocks(K kernel, size_t lds) {
   int dev = 0;
   int cus = 256;
   int per_cu = 2;
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess ||
       per_cu < 1) {
-    per_cu = 2;
+    per_cu = 1;
   }
   return cus * per_cu;
 }
@@ -760,8 +844,14 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       idx_entries += (size_t)(a.absorb_index_n + 1);
     }
     const size_t lds = sizeof(unsigned short) * idx_entries;
+    if (lds > (size_t)(160 * 1024 - 64)) {
+      return hipErrorInvalidValue; /* the ABI drops an index before this can happen */
+    }
     auto launch = [&](auto kernel) {
-      int grid = resident_blocks(kernel);
+      /* (the indexes of two distinct large tables can exceed the 64 KB default) */
+      (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      int grid = resident_blocks(kernel, lds);
       if (a.blocks_per_cu > 0) {
         /* the caller knows how little work there is: fewer resident waves per
          * SIMD shorten every history's serial chain (see launch_solve_tiled) */

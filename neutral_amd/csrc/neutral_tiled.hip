@@ -4,19 +4,24 @@
  *
  * Why (profiles/r01/ablate_tally.log): once lane divergence is gone, every
  * facet-heavy deck is bound by the memory-side f64 atomic request rate
- * (~1.3-2.1e10 scattered atomics/s for the whole chip), e.g. 86 % of the stream
+ * (~2.3e10 scattered atomics/s for the whole chip), e.g. 86 % of the stream
  * deck's time and all of csp's.  Atomics into LDS do not have that ceiling, but
  * a 400^2 f64 tally (1.28 MB) does not fit 160 KB of LDS -- a window of it does,
  * if the particles a workgroup works on are spatially close.  So, per timestep:
  *
  *   0. the variant works on a private array of 80-byte particle RECORDS kept in
  *      tile order from step to step (neutral_kernels.h: ParticleRec); the SoA
- *      store of the interface is imported once and exported on demand;
- *   1. tile_key / radix sort / tile_bounds / tile_chunks   the LIVE records
- *      sorted by the 16x16-cell tile they start the step in (rocPRIM radix sort
- *      over the log2(#tiles) key bits; dead particles get the largest key and
- *      drop out of the work list instead of being re-scanned every step,
- *      omp3/neutral.c:91-93);
+ *      store of the interface is imported once and kept current by the kernels
+ *      that finish a history (or written back on demand, lazy export);
+ *   1. tile_count / tile_scan / tile_scatter / tile_chunks   an own COUNTING SORT
+ *      of the LIVE records by the T x T-cell tile they start the step in (one
+ *      histogram pass over the 4-byte record summaries, one scan over the tiles,
+ *      one placement pass: every workgroup reserves its share of each tile's
+ *      range with one atomic per tile it holds; dead particles get the last
+ *      bucket and drop out of the work list instead of being re-scanned every
+ *      step, omp3/neutral.c:91-93).  T is chosen per problem from the particle
+ *      density (16 for the dense BASELINE configurations ... 128 for the
+ *      reference's decks as shipped, 4000^2 cells and 1e6 particles);
  *   2. stream_kernel   1024-thread persistent workgroups take chunks of one
  *      tile's particles.  A 128x128-cell f64 window of the tally centred on the
  *      tile lives in LDS (128 KB): facet and census tallies inside it are
@@ -24,12 +29,16 @@
  *      is flushed to the mesh (coalesced rows) when the workgroup moves to
  *      another tile.  Lanes stream their particle (prologue, facets, census)
  *      and are refilled from the chunk like in K2.  A particle whose next event
- *      is a collision is SUSPENDED: its record is stored and its id appended to
- *      the collision queue.  A particle that leaves the window with many
- *      facets still ahead (fast particles: the stream deck crosses 553 cells per
- *      step) is handed to the NEXT PASS of steps 1-2, which sorts the migrants by
- *      the tile they have reached; passes repeat until nobody migrates;
- *   3. history_regroup_kernel (K2) finishes the queued histories with dense
+ *      is a collision is SUSPENDED: its record is stored and marked for the
+ *      collision stage.  A particle that leaves the window with many facets
+ *      still ahead (fast particles: the stream deck crosses 553 cells per step)
+ *      is handed to the NEXT PASS of steps 1-2, which sorts the migrants by the
+ *      tile they have reached and works on their records in place; passes
+ *      repeat until nobody migrates.  The host does not wait between passes: it
+ *      enqueues as many as the previous timestep needed plus one (a pass without
+ *      migrants costs four empty launches) and looks at the migrant counter once,
+ *      together with the step's event counters;
+ *   3. history_regroup_kernel (K2) finishes the suspended histories with dense
  *      collision waves (neutral_history.h: resume()).
  *
  * Every particle executes the same event bodies with the same RNG counters as
@@ -37,9 +46,7 @@
  * the tally changes.
  */
 #include <cstdlib>
-#include <cstring> /* before rocprim: its texture iterator calls ::memset on the host */
-
-#include <rocprim/rocprim.hpp>
+#include <cstring>
 
 #include "neutral_kernels.h"
 
@@ -49,9 +56,7 @@
 
 namespace neutral {
 
-constexpr int kTile = kTileCells;                  /* cells per tile edge (16) */
 constexpr int kWindow = 128;                       /* cells per LDS window edge */
-constexpr int kMargin = (kWindow - kTile) / 2;     /* window reach beyond the tile */
 #ifndef NEUTRAL_STREAM_BLOCK
 #define NEUTRAL_STREAM_BLOCK 1024
 #endif
@@ -78,47 +83,191 @@ constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
 #endif
 constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
 constexpr int kSortBlock = 256;
+/* counting sort: records one workgroup histograms and places at a time, and the
+ * largest number of buckets (tiles + 1) it keeps in LDS (count + base: 64 KB);
+ * meshes with more tiles than that place with one global atomic per record */
+constexpr int kSortItems = 16;
+constexpr int kSortSegment = kSortBlock * kSortItems;
+constexpr int kSortLdsBins = 8192;
 
 enum Ctrl : int {
   kCtrlChunkHead = 0,
   kCtrlNumChunks = 1,
   kCtrlCollideCount = 2,
   kCtrlActive = 3,
-  kCtrlMigrants = 4,
+  kCtrlMigrants = 4,   /* histories the last stream pass handed to the next one */
+  kCtrlPassesUsed = 5, /* stream passes of this step that had work */
 };
-constexpr int kMaxStreamPasses = 64;
 /* a history leaves its window for another pass only if about this many facet
  * crossings still lie ahead; shorter tails finish with global atomics */
 #ifndef NEUTRAL_MIGRATE_MIN_FACETS
 #define NEUTRAL_MIGRATE_MIN_FACETS 8.0
 #endif
 constexpr double kMigrateMinFacets = NEUTRAL_MIGRATE_MIN_FACETS;
-/* a tile (or the last chunk of one) with fewer particles than this tallies straight
- * to HBM: flushing a 16 384-cell window costs more than the few atomics it would
- * save, and its particles never migrate.  Such tiles share chunks with their
- * neighbours in the sorted order (tile_chunks_kernel), so sparse problems degrade
- * to the plain event-regrouped behaviour, not below it */
-constexpr int kWindowMinParticles = 2048;
+constexpr int kMaxStreamPasses = 256;
 
-__device__ __forceinline__ int tile_of(const TiledArgs& t, int cellx, int celly) {
-  return (celly / kTile) * t.tiles_x + (cellx / kTile);
+/* ---- 1. counting sort of the live records by tile ----------------------------------- */
+
+constexpr unsigned kNoBucket = 0xFFFFFFFFu;
+
+/* bucket of a record in this pass, from its 4-byte summary: its tile when it takes
+ * part (pass 0: every live particle; later passes: the migrants of the pass before);
+ * in pass 0 the dead go to the last bucket (they are carried over behind the live
+ * ones); in later passes everything else stays where it is */
+__device__ __forceinline__ unsigned sort_bucket(const TiledArgs& t, unsigned summary) {
+  const int state = (int)(summary >> 30);
+  if (t.pass == 0) {
+    return (state != kRecDead) ? (summary & 0x3FFFFFFFu) : (unsigned)t.ntiles;
+  }
+  return (state == kRecMigrate) ? (summary & 0x3FFFFFFFu) : kNoBucket;
 }
 
-/* ---- 1. sort of the live particle ids by tile ----------------------------------- */
+/* the summaries a pass sorts: last step's in pass 0, this step's (written by the
+ * stream kernel next to the records it hands on) afterwards */
+__device__ __forceinline__ const unsigned* sort_summaries(const TiledArgs& t) {
+  return (t.pass == 0) ? t.info_in : t.info_out;
+}
 
-/* key of every record: its tile when it takes part in this pass, ntiles
- * otherwise (sorts last).  Pass 0: every live particle; later passes: migrants. */
-__global__ __launch_bounds__(kSortBlock) void tile_key_kernel(SolveArgs a, TiledArgs t) {
-  const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  if (i < a.nparticles) {
-    const unsigned v = t.info_in[i];
-    const int state = (int)(v >> 30);
-    const bool active = (t.pass == 0) ? (state != kRecDead) : (state == kRecMigrate);
-    t.keys_in[i] = active ? (v & 0x3FFFFFFFu) : (unsigned)t.ntiles;
+/* a later pass with nobody to move: its kernels return at once */
+__device__ __forceinline__ bool pass_is_empty(const TiledArgs& t) {
+  return t.pass > 0 && t.ctrl[kCtrlMigrants] == 0;
+}
+
+/* histogram: tile_count[b] += records of bucket b (tile_count is zero on entry:
+ * tile_scan_kernel clears what it has consumed) */
+__global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, TiledArgs t) {
+  extern __shared__ unsigned s_bins[];
+  if (pass_is_empty(t)) {
+    return;
+  }
+  const int nbins = t.ntiles + 1;
+  const bool in_lds = nbins <= kSortLdsBins;
+  if (in_lds) {
+    for (int b = threadIdx.x; b < nbins; b += kSortBlock) {
+      s_bins[b] = 0;
+    }
+    __syncthreads();
+  }
+  const unsigned* info = sort_summaries(t);
+  const long long base = (long long)blockIdx.x * kSortSegment;
+#pragma unroll 4
+  for (int k = 0; k < kSortItems; ++k) {
+    const long long i = base + (long long)k * kSortBlock + threadIdx.x;
+    if (i < a.nparticles) {
+      const unsigned b = sort_bucket(t, info[i]);
+      if (b != kNoBucket) {
+        atomicAdd(in_lds ? &s_bins[b] : &t.tile_count[b], 1u);
+      }
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += kSortBlock) {
+      const unsigned c = s_bins[b];
+      if (c) {
+        atomicAdd(&t.tile_count[b], c);
+      }
+    }
   }
 }
 
-/* records that sit this pass out are carried over behind the active ones */
+/* single workgroup: tile_offset[k] = first sorted position of bucket k, for
+ * k = 0..ntiles+1 (empty tiles included); tile_cursor = the same, consumed by the
+ * placement; tile_count is cleared for the next pass */
+__global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
+  __shared__ unsigned s_part[1024];
+  const int tid = threadIdx.x;
+  const int n = t.ntiles + 2;
+  const int per = (n + 1023) / 1024;
+  const int lo = (tid * per < n) ? tid * per : n;
+  const int hi = (lo + per < n) ? lo + per : n;
+  unsigned sum = 0;
+  for (int i = lo; i < hi; ++i) {
+    sum += (i <= t.ntiles) ? t.tile_count[i] : 0u;
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) { /* Hillis-Steele inclusive scan */
+    const unsigned c0 = (tid >= off) ? s_part[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += c0;
+    __syncthreads();
+  }
+  unsigned run = s_part[tid] - sum; /* exclusive */
+  for (int i = lo; i < hi; ++i) {
+    const unsigned c = (i <= t.ntiles) ? t.tile_count[i] : 0u;
+    t.tile_offset[i] = run;
+    t.tile_cursor[i] = run;
+    if (i <= t.ntiles) {
+      t.tile_count[i] = 0;
+    }
+    run += c;
+  }
+}
+
+/* placement: order[position] = record index, positions of a bucket contiguous.  A
+ * workgroup histograms its segment in LDS, reserves its part of every bucket it
+ * holds with ONE returning atomic per bucket, and ranks its records inside the
+ * reservation with LDS atomics.  (The order inside a tile is whatever the atomics
+ * make it: nothing depends on it -- histories are independent and the tally is a
+ * sum.) */
+__global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, TiledArgs t) {
+  extern __shared__ unsigned s_bins[]; /* count/rank [nbins], base [nbins] */
+  if (pass_is_empty(t)) {
+    return;
+  }
+  const int nbins = t.ntiles + 1;
+  const bool in_lds = nbins <= kSortLdsBins;
+  unsigned* s_rank = s_bins;
+  unsigned* s_base = s_bins + nbins;
+  const unsigned* info = sort_summaries(t);
+  const long long base = (long long)blockIdx.x * kSortSegment;
+  unsigned bucket[kSortItems];
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    const long long i = base + (long long)k * kSortBlock + threadIdx.x;
+    bucket[k] = (i < a.nparticles) ? sort_bucket(t, info[i]) : kNoBucket;
+  }
+  if (!in_lds) {
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+      if (bucket[k] != kNoBucket) {
+        const unsigned pos = atomicAdd(&t.tile_cursor[bucket[k]], 1u);
+        t.order[pos] = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+      }
+    }
+    return;
+  }
+  for (int b = threadIdx.x; b < nbins; b += kSortBlock) {
+    s_rank[b] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    if (bucket[k] != kNoBucket) {
+      atomicAdd(&s_rank[bucket[k]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins; b += kSortBlock) {
+    const unsigned c = s_rank[b];
+    if (c) {
+      s_base[b] = atomicAdd(&t.tile_cursor[b], c);
+      s_rank[b] = 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    if (bucket[k] != kNoBucket) {
+      const unsigned pos = s_base[bucket[k]] + atomicAdd(&s_rank[bucket[k]], 1u);
+      t.order[pos] = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+    }
+  }
+}
+
+/* pass 0: the records that sit the step out (the dead) are carried over behind the
+ * live ones, which the stream kernel writes in tile order */
 __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, TiledArgs t) {
   const unsigned first_inactive = t.tile_offset[t.ntiles];
   const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
@@ -165,7 +314,8 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
 /* SoA store -> records, in id order */
 __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
                                                                     unsigned* info, int tiles_x,
-                                                                    int x_off, int y_off, int n) {
+                                                                    int tile_shift, int x_off,
+                                                                    int y_off, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   if (i < n) {
     ParticleRec r;
@@ -182,7 +332,8 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
     r.id = (unsigned)i;
     r.dead = p.dead[i];
     rec[i] = r;
-    info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x);
+    info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x,
+                           tile_shift);
   }
 }
 
@@ -218,23 +369,9 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
   }
 }
 
-/* tile_offset[k] = first position of key k in the sorted keys, for k = 0..ntiles+1
- * (empty tiles included): position i starts every key in (keys[i-1], keys[i]] */
-__global__ __launch_bounds__(kSortBlock) void tile_bounds_kernel(SolveArgs a, TiledArgs t) {
-  const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  if (i > a.nparticles) {
-    return;
-  }
-  const int prev = (i == 0) ? -1 : (int)t.keys_out[i - 1];
-  const int cur = (i == a.nparticles) ? t.ntiles + 1 : (int)t.keys_out[i];
-  for (int k = prev + 1; k <= cur; ++k) {
-    t.tile_offset[k] = (unsigned)i;
-  }
-}
-
 /* single workgroup: the chunk list, from the tile populations.
  *
- * A tile with at least kWindowMinParticles particles is cut into chunks of its own
+ * A tile with at least window_min_particles particles is cut into chunks of its own
  * (they stream with the LDS window centred on the tile).  Tiles below that are not
  * worth a window, so they need no chunk of their own either: consecutive sparse
  * tiles -- contiguous in the sorted order -- are MERGED into un-windowed chunks of
@@ -273,7 +410,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
           if (chunk < (unsigned)t.max_chunks) {
             /* the last chunk of a dense tile may be too small for a window */
             t.chunks[chunk] = make_uint4(b, e, tile,
-                                         (windowed && (e - b) >= (unsigned)kWindowMinParticles) ? 1u : 0u);
+                                         (windowed && (e - b) >= (unsigned)t.window_min_particles) ? 1u : 0u);
           }
           chunk++;
         }
@@ -282,7 +419,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
     for (int i = lo; i < hi; ++i) {
       const unsigned begin = t.tile_offset[i];
       const unsigned end = t.tile_offset[i + 1];
-      if (end - begin >= (unsigned)kWindowMinParticles) {
+      if (end - begin >= (unsigned)t.window_min_particles) {
         emit(run_begin, run_end, 0u, 0u);
         run_begin = run_end = end;
         emit(begin, end, (unsigned)i, 1u);
@@ -308,10 +445,15 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   }
   if (tid == 1023) {
     t.ctrl[kCtrlNumChunks] = s_chunks[1023];
-    t.ctrl[kCtrlActive] = t.tile_offset[t.ntiles];
+    t.ctrl[kCtrlActive] = nactive;
     t.ctrl[kCtrlChunkHead] = 0;
     t.ctrl[kCtrlCollideCount] = 0;
     t.ctrl[kCtrlMigrants] = 0;
+    if (t.pass == 0) {
+      t.ctrl[kCtrlPassesUsed] = 1;
+    } else if (nactive > 0) {
+      t.ctrl[kCtrlPassesUsed] = (unsigned)t.pass + 1u;
+    }
   }
 }
 
@@ -343,6 +485,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   __shared__ int s_windowed;
   __shared__ int s_cursor;
 
+  if (a.abort_flag && *a.abort_flag) {
+    return; /* the cached view of the cs tables is stale: the host re-runs the step */
+  }
   /* stage the cs index(es), zero the window */
   CsLookup<const unsigned short*> ix{nullptr, nullptr};
   {
@@ -410,8 +555,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         flush_window(a, window, win_ox, win_oy);
       }
       cur_tile = chunk_tile;
-      win_ox = (cur_tile % t.tiles_x) * kTile - kMargin;
-      win_oy = (cur_tile / t.tiles_x) * kTile - kMargin;
+      /* the window reaches (128 - T) / 2 cells beyond the T x T tile on every side */
+      const int margin = (kWindow - (1 << t.tile_shift)) >> 1;
+      win_ox = ((cur_tile % t.tiles_x) << t.tile_shift) - margin;
+      win_oy = ((cur_tile / t.tiles_x) << t.tile_shift) - margin;
       __syncthreads();
     }
     /* an un-windowed chunk sees a window that contains no cell */
@@ -447,8 +594,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             w_processed += (unsigned)((n_empty < left) ? n_empty : left);
           }
           if (!has && mine < chunk_end) {
-            pid = mine; /* this history's slot in rec_out */
-            load_record(h, a, t.rec_in[t.order[mine]]);
+            /* pass 0 reads last step's records through the sorted order and writes
+             * this step's in tile order; later passes work on their migrants in place */
+            const unsigned src = t.order[mine];
+            pid = (t.pass == 0) ? mine : (int)src; /* this history's slot in rec_out */
+            load_record(h, a, (t.pass == 0) ? t.rec_in[src] : t.rec_out[src]);
             if (t.pass == 0) {
               prologue<kSameTables>(h, a, ix);
             } else {
@@ -517,7 +667,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           store_record(h, a, t.rec_out[pid], kRecIdle);
-          t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x);
+          t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
+                                         t.tile_shift);
+          if (a.export_soa) {
+            store_particle(h, a, (int)h.id); /* the interface's arrays stay current */
+          }
           has = false;
           did_census = (h.ev == kEvCensus);
         }
@@ -525,7 +679,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       /* histories handed on: the record carries the state; migrants are counted */
       if (park != kRecIdle) {
         store_record(h, a, t.rec_out[pid], park);
-        t.info_out[pid] = slot_summary(park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x);
+        t.info_out[pid] = slot_summary(park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
+                                       t.tile_shift);
         has = false;
       }
       w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
@@ -563,19 +718,6 @@ size_t tiled_lds_bytes(const SolveArgs& a) {
   return (lds + 15) & ~(size_t)15;
 }
 
-size_t tiled_sort_temp_bytes(int nparticles, int ntiles) {
-  unsigned bits = 1;
-  while ((1u << bits) <= (unsigned)ntiles) {
-    bits++;
-  }
-  size_t bytes = 0;
-  unsigned* none = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, none, none,
-                                  rocprim::counting_iterator<unsigned>(0u), none,
-                                  (size_t)nparticles, 0u, bits, (hipStream_t) nullptr);
-  return bytes;
-}
-
 int tiled_chunk_particles(int nparticles, int compute_units) {
   /* about six chunks per workgroup when every particle is live */
 #ifndef NEUTRAL_CHUNKS_PER_WG
@@ -587,18 +729,55 @@ int tiled_chunk_particles(int nparticles, int compute_units) {
   return (int)c;
 }
 
-void tiled_geometry(int nx, int ny, int nparticles, int* tiles_x, int* tiles_y, int* max_chunks) {
-  *tiles_x = (nx + kTile - 1) / kTile;
-  *tiles_y = (ny + kTile - 1) / kTile;
+int tiled_tile_shift(int nx, int ny, int nparticles) {
+  /* Tile edge T = 16 << k cells under the fixed 128-cell window.  A tile is worth a
+   * window when enough particles stream through it to pay for the window's flush; the
+   * estimate is the mean particle density (particles per cell): 16-cell tiles from 8
+   * per cell on (the BASELINE configurations hold 60-600), 128-cell tiles -- the
+   * window itself, no margin -- below 0.5 (the reference's decks as shipped: 4000^2
+   * cells, 1e6 particles, 0.06 per cell; their particles cross thousands of cells per
+   * step and enter every window at an edge anyway).  NEUTRAL_TILE_CELLS overrides. */
+  const char* force = getenv("NEUTRAL_TILE_CELLS");
+  if (force) {
+    const int cells = atoi(force);
+    for (int shift = 4; shift <= 7; ++shift) {
+      if (cells == (1 << shift)) {
+        return shift;
+      }
+    }
+  }
+  const double density = (double)nparticles / ((double)nx * (double)ny);
+  return (density >= 8.0) ? 4 : (density >= 2.0) ? 5 : (density >= 0.5) ? 6 : 7;
+}
+
+int tiled_window_min_particles(int tile_shift) {
+  /* particles a chunk must hold to stream under a window: a window flush costs up
+   * to 16 384 (coalesced) atomics, a particle saves one scattered atomic per facet
+   * it crosses inside -- a few dozen for a 16-cell tile's short flights, a hundred
+   * and more when it crosses a whole 128-cell window */
+  const char* force = getenv("NEUTRAL_WINDOW_MIN_PARTICLES");
+  if (force) {
+    return atoi(force);
+  }
+  return 2048 >> (tile_shift - 4);
+}
+
+void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
+                    int* max_chunks) {
+  const int tile = 1 << tile_shift;
+  *tiles_x = (nx + tile - 1) / tile;
+  *tiles_y = (ny + tile - 1) / tile;
   /* every tile can end with one partial chunk */
   *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesMin + 1;
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 int tiles_x, int x_off, int y_off, int n, hipStream_t stream) {
+                                 int tiles_x, int tile_shift, int x_off, int y_off, int n,
+                                 hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, p, rec, info, tiles_x, x_off, y_off, n);
+                       dim3(kSortBlock), 0, stream, p, rec, info, tiles_x, tile_shift, x_off, y_off,
+                       n);
   }
   return hipGetLastError();
 }
@@ -615,20 +794,47 @@ hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
   return hipGetLastError();
 }
 
+/* one stream pass: counting sort of the records that take part, chunk list, stream kernel */
+static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass, int cus,
+                                      size_t lds, hipStream_t stream, hipEvent_t after_sort) {
+  t.pass = pass;
+  t.allow_migrate = (pass + 1 < kMaxStreamPasses) ? 1 : 0;
+  const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
+  const int grid_seg = (a.nparticles + kSortSegment - 1) / kSortSegment;
+  const int nbins = t.ntiles + 1;
+  const size_t lds_bins = (nbins <= kSortLdsBins) ? sizeof(unsigned) * (size_t)nbins : 0;
+  hipLaunchKernelGGL(tile_count_kernel, dim3(grid_seg), dim3(kSortBlock), lds_bins, stream, a, t);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, t);
+  hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_seg), dim3(kSortBlock), 2 * lds_bins, stream, a,
+                     t);
+  hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
+  if (pass == 0) {
+    /* (grid sized for the worst case: no record takes part) */
+    hipLaunchKernelGGL(copy_inactive_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
+    if (after_sort) {
+      (void)hipEventRecord(after_sort, stream);
+    }
+  }
+  /* one 1024-thread workgroup per CU (the window takes most of the LDS) */
+  if (a.same_tables) {
+    hipLaunchKernelGGL(stream_kernel<true>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+  } else {
+    hipLaunchKernelGGL(stream_kernel<false>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
-                              hipEvent_t after_sort, hipEvent_t after_stream,
-                              hipEvent_t after_collect, int* npasses) {
-  if (npasses) {
-    *npasses = 0;
+                              const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
+                              hipEvent_t after_stream, hipEvent_t after_collect,
+                              int* passes_enqueued, int* host_syncs) {
+  if (passes_enqueued) {
+    *passes_enqueued = first_pass;
   }
   if (a.nparticles <= 0) {
     return hipSuccess;
   }
   const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
-  unsigned bits = 1;
-  while ((1u << bits) <= (unsigned)t.ntiles) {
-    bits++;
-  }
   int dev = 0;
   int cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -640,62 +846,47 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute((const void*)stream_kernel<false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * sizeof(unsigned) * kSortLdsBins));
 
-  for (int pass = 0; pass < kMaxStreamPasses; ++pass) {
-    t.pass = pass;
-    t.allow_migrate = (pass + 1 < kMaxStreamPasses) ? 1 : 0;
-    /* 1. keys -> stable radix sort of (key, record index) -> tile bounds -> chunks.
-     * Only the low bits that can differ are sorted. */
-    hipLaunchKernelGGL(tile_key_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
-    size_t temp_bytes = t.sort_temp_bytes;
-    hipError_t err = rocprim::radix_sort_pairs(
-        t.sort_temp, temp_bytes, t.keys_in, t.keys_out, rocprim::counting_iterator<unsigned>(0u),
-        t.order, (size_t)a.nparticles, 0u, bits, stream);
-    if (err != hipSuccess) {
-      return err;
+  int pass = first_pass;
+  if (plan.stream_passes > 0 && first_pass == 0) {
+    /* steady state: as many passes as the last step needed plus one, without looking
+     * at the migrant counter in between (the caller reads it once, at the end) */
+    for (; pass < plan.stream_passes && pass < kMaxStreamPasses; ++pass) {
+      const hipError_t err = enqueue_stream_pass(a, t, pass, cus, lds, stream, after_sort);
+      if (err != hipSuccess) {
+        return err;
+      }
     }
-    hipLaunchKernelGGL(tile_bounds_kernel, dim3((a.nparticles + 1 + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, a, t);
-    hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
-    /* (grid sized for the worst case: no record takes part) */
-    hipLaunchKernelGGL(copy_inactive_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
-    if (pass == 0 && after_sort) {
-      (void)hipEventRecord(after_sort, stream);
+  } else {
+    /* first step of a problem, or a step that outran the plan: one look per pass */
+    for (; pass < kMaxStreamPasses;) {
+      hipError_t err = enqueue_stream_pass(a, t, pass, cus, lds, stream, after_sort);
+      if (err != hipSuccess) {
+        return err;
+      }
+      ++pass;
+      unsigned migrants = 0;
+      err = hipMemcpyAsync(&migrants, &t.ctrl[kCtrlMigrants], sizeof(unsigned),
+                           hipMemcpyDeviceToHost, stream);
+      if (err == hipSuccess) {
+        err = hipStreamSynchronize(stream);
+      }
+      if (err != hipSuccess) {
+        return err;
+      }
+      if (host_syncs) {
+        ++*host_syncs;
+      }
+      if (migrants == 0) {
+        break;
+      }
     }
-
-    /* 2. one 1024-thread workgroup per CU (the window takes most of the LDS) */
-    if (a.same_tables) {
-      hipLaunchKernelGGL(stream_kernel<true>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
-    } else {
-      hipLaunchKernelGGL(stream_kernel<false>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
-    }
-    err = hipGetLastError();
-    if (err != hipSuccess) {
-      return err;
-    }
-    ParticleRec* swap = t.rec_in; /* this pass's output is the next stage's input */
-    t.rec_in = t.rec_out;
-    t.rec_out = swap;
-    unsigned* swap_info = t.info_in;
-    t.info_in = t.info_out;
-    t.info_out = swap_info;
-
-    unsigned migrants = 0;
-    err = hipMemcpyAsync(&migrants, &t.ctrl[kCtrlMigrants], sizeof(unsigned),
-                         hipMemcpyDeviceToHost, stream);
-    if (err != hipSuccess) {
-      return err;
-    }
-    err = hipStreamSynchronize(stream);
-    if (err != hipSuccess) {
-      return err;
-    }
-    if (npasses) {
-      *npasses = pass + 1;
-    }
-    if (migrants == 0) {
-      break;
-    }
+  }
+  if (passes_enqueued) {
+    *passes_enqueued = pass;
   }
   if (after_stream) {
     (void)hipEventRecord(after_stream, stream);
@@ -704,17 +895,13 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   /* 3. the suspended histories: K2 over the collision queue; it counts its
    * events in the second StepCounters record */
   hipLaunchKernelGGL(collect_suspended_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t,
-                     t.info_in);
+                     t.info_out);
   if (after_collect) {
     (void)hipEventRecord(after_collect, stream);
   }
   SolveArgs c = a;
-  {
-    /* A collider is a serial chain of ~10^3 collisions; with few of them the stage
-     * lasts one chain, and a chain runs faster the fewer waves share its SIMD
-     * (csp, per chain: 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two:
-     * profiles/r01f).  So a queue that fits one (two) workgroup(s) per CU gets
-     * exactly that many; anything larger fills the chip as usual. */
+  c.blocks_per_cu = plan.blocks_per_cu;
+  if (plan.blocks_per_cu < 0) {
     unsigned queued = 0;
     hipError_t qe = hipMemcpyAsync(&queued, &t.ctrl[kCtrlCollideCount], sizeof(unsigned),
                                    hipMemcpyDeviceToHost, stream);
@@ -724,8 +911,12 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     if (qe != hipSuccess) {
       return qe;
     }
-    const unsigned lanes_per_block_row = (unsigned)cus * 256u;
-    c.blocks_per_cu = (queued <= lanes_per_block_row) ? 1 : (queued <= 2u * lanes_per_block_row) ? 2 : 0;
+    if (host_syncs) {
+      ++*host_syncs;
+    }
+    c.blocks_per_cu = tiled_collision_blocks_per_cu(queued, cus);
+  }
+  {
     const char* force = getenv("NEUTRAL_K2_BLOCKS_PER_CU"); /* experiment knob */
     if (force) {
       c.blocks_per_cu = atoi(force);
@@ -738,9 +929,10 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
   c.queue_len = &t.ctrl[kCtrlCollideCount];
-  c.rec = t.rec_in;
-  c.slot_info = t.info_in;
+  c.rec = t.rec_out;
+  c.slot_info = t.info_out;
   c.tiles_x = t.tiles_x;
+  c.tile_shift = t.tile_shift;
   c.susp = t.susp;
   if (t.fine_index && c.same_tables) {
     c.scatter_index = t.fine_index;
@@ -749,6 +941,16 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     c.index_shift = t.fine_index_shift;
   }
   return launch_solve(c, kVariantEventSorted, stream);
+}
+
+int tiled_collision_blocks_per_cu(unsigned queued, int cus) {
+  /* A collider is a serial chain of ~10^3 collisions; with few of them the stage
+   * lasts one chain, and a chain runs faster the fewer waves share its SIMD
+   * (csp, per chain: 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two:
+   * profiles/r01f).  So a queue that fits one (two) workgroup(s) per CU gets
+   * exactly that many; anything larger fills the chip as usual (0). */
+  const unsigned lanes_per_block_row = (unsigned)cus * 256u;
+  return (queued <= lanes_per_block_row) ? 1 : (queued <= 2u * lanes_per_block_row) ? 2 : 0;
 }
 
 }  // namespace neutral

@@ -64,7 +64,9 @@ class StepStats(C.Structure):
                 ("collide_ms", C.c_double), ("stream_facets", C.c_uint64),
                 ("stream_census", C.c_uint64), ("suspended", C.c_uint64),
                 ("aborted", C.c_uint64), ("stream_passes", C.c_int),
-                ("requeued", C.c_uint64), ("collide_passes", C.c_uint64)]
+                ("requeued", C.c_uint64), ("collide_passes", C.c_uint64),
+                ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
+                ("tile_cells", C.c_int)]
 
 
 # every symbol include/neutral_hip.h declares
@@ -79,6 +81,7 @@ ABI_SYMBOLS = (
     "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
     "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
+    "neutral_hip_invalidate_particles",
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
@@ -120,6 +123,7 @@ _lib.neutral_hip_reinject_particles.argtypes = [
 _lib.neutral_hip_free_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_set_lazy_export.argtypes = [C.c_int]
 _lib.neutral_hip_sync_particles.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_invalidate_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -322,6 +326,7 @@ class Simulation:
         torch.cuda.set_device(self.device)
         set_device(device)
         set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.variant = variant
         if variant is not None:
             set_variant(variant)
         first, count = shard if shard is not None else (0, problem.nparticles)
@@ -366,7 +371,11 @@ class Simulation:
 
     def step(self, master_key: int) -> StepResult:
         p = self.p
+        # variant and pid base are process-global in the library: re-apply this
+        # simulation's own before every call (several Simulations may be alive)
         set_pid_base(self.pid_base)
+        if self.variant is not None:
+            set_variant(self.variant)
         facets, collisions = C.c_uint64(0), C.c_uint64(0)
         solve_transport_2d(
             p.nx - 2 * p.pad, p.ny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, p.x_off,

@@ -1,0 +1,246 @@
+"""The tiled pipeline's own machinery, on a real MI355X (`-m gpu`): the counting
+sort and the tile edge chosen per problem, stream passes enqueued without host
+round trips, the SoA arrays kept current by the kernels (and re-imported when a
+caller rewrites them), the cached view of the cross-section tables.
+
+Everything here is checked against the over-particle kernel (variant 0), which
+test_hip_parity.py checks against the CPU oracle: same particle bits, same event
+counts, tallies equal up to summation order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
+
+
+@pytest.fixture()
+def iface():
+    from neutral_amd import interface
+    interface.set_quiet(True)
+    interface.set_lazy_export(False)
+    interface.set_variant(interface.VARIANT_OVER_PARTICLE)
+    return interface
+
+
+def _run(iface, prob, cs, variant, steps, between=None, **sim_kw):
+    sim = iface.Simulation(prob, *cs, variant=variant, **sim_kw)
+    sim.inject()
+    ev, stats = [], []
+    for tt in range(1, steps + 1):
+        if between is not None:
+            between(sim, tt)
+        r = sim.step(tt)
+        ev.append((r.nprocessed, r.facets, r.collisions, r.census))
+        stats.append(r.stats)
+    out = (sim.particle_arrays(), sim.tally_host(), ev, stats)
+    sim.close()
+    return out
+
+
+def _loaded_hip_runtime():
+    """The HIP runtime this process already uses (torch's), by its mapped path."""
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            return C.CDLL(line.split()[-1])
+    raise RuntimeError("no HIP runtime mapped")
+
+
+def _same(a, b):
+    pa, ta, ea, _ = a
+    pb, tb, eb, _ = b
+    assert ea == eb
+    for f in pa:
+        assert np.array_equal(pa[f], pb[f]), f
+    assert np.linalg.norm(ta - tb) / np.linalg.norm(ta) < 1e-13
+
+
+@pytest.mark.parametrize("deck,nx,n,dt,steps", [
+    ("stream", 400, 30000, None, 2),     # long flights: many windows per history
+    ("csp", 100, 50000, 1.0e-6, 3),      # vacuum + dense block
+    ("split", 200, 60000, 5.0e-7, 2),
+    ("stream", 1000, 20000, None, 1),    # sparse: 0.02 particles per cell
+])
+@pytest.mark.parametrize("tile", [16, 32, 64, 128])
+def test_every_tile_edge_gives_the_same_histories(iface, make_problem, cs, monkeypatch, deck, nx,
+                                                  n, dt, steps, tile):
+    """The tile edge (16..128 cells under the 128-cell window) only decides where a
+    tally is accumulated and how often a history changes windows.  A low window
+    threshold makes the small test problems stream under windows at all."""
+    kw = dict(nx=nx, nparticles=n, iterations=steps)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    want = _run(iface, prob, cs, 0, steps)
+    monkeypatch.setenv("NEUTRAL_TILE_CELLS", str(tile))
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    got = _run(iface, prob, cs, 2, steps)
+    _same(want, got)
+    assert all(s.tile_cells == tile for s in got[3])
+    assert all(s.aborted == 0 for s in got[3])
+
+
+def test_tile_edge_follows_the_particle_density(iface, make_problem, cs):
+    for deck, nx, n, want in (("csp", 100, 100000, 16), ("csp", 200, 100000, 32),
+                              ("csp", 400, 100000, 64), ("stream", 1000, 20000, 128)):
+        prob = make_problem(deck, nx=nx, nparticles=n, iterations=1)
+        sim = iface.Simulation(prob, *cs, variant=2)
+        sim.inject()
+        assert sim.step(1).stats.tile_cells == want, (deck, nx, n)
+        sim.close()
+
+
+def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, monkeypatch):
+    """From the second step of a problem on, stream passes, collision queue and
+    collision stage are enqueued on what the step before needed: the only wait is the
+    read-back of the counters.  The stream deck makes every history migrate through
+    several windows, i.e. several passes per step."""
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    prob = make_problem("stream", nx=400, nparticles=30000, iterations=4)
+    want = _run(iface, prob, cs, 0, 4)
+    got = _run(iface, prob, cs, 2, 4)
+    _same(want, got)
+    stats = got[3]
+    assert stats[0].stream_passes > 2, "the case no longer migrates"
+    assert stats[0].host_syncs > 1          # first step: one look per pass
+    for s in stats[1:]:
+        assert s.host_syncs == 1, (s.host_syncs, s.stream_passes, s.stream_passes_enqueued)
+        assert s.stream_passes <= s.stream_passes_enqueued
+
+    prob = make_problem("csp", nx=100, nparticles=50000, iterations=4, dt=1.0e-6)
+    got = _run(iface, prob, cs, 2, 4)
+    assert [s.host_syncs for s in got[3][1:]] == [1, 1, 1]
+
+
+def test_a_step_that_outruns_the_plan_is_finished(iface, make_problem, cs, monkeypatch):
+    """Step 1 at a tiny dt needs one stream pass; step 2 (same store, ten times the
+    dt through a second problem object) needs several more than were enqueued."""
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    short = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-9)
+    long_ = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-7)
+
+    def lengthen(sim, tt):
+        if tt == 2:
+            sim.p = long_
+
+    want = _run(iface, short, cs, 0, 2, between=lengthen)
+    got = _run(iface, short, cs, 2, 2, between=lengthen)
+    _same(want, got)
+    s1, s2 = got[3]
+    assert s1.stream_passes == 1
+    assert s2.stream_passes > s2.stream_passes_enqueued - 1 and s2.stream_passes > 2
+    assert s2.host_syncs > 1
+
+
+def test_the_soa_arrays_are_current_after_every_step(iface, make_problem, cs):
+    """Default (eager) mode: the kernels that end a history write it to the
+    interface's arrays; nothing is pending when solve_transport_2d returns."""
+    prob = make_problem("csp", nx=100, nparticles=50000, iterations=3, dt=1.0e-6)
+    ref = iface.Simulation(prob, *cs, variant=0)
+    sim = iface.Simulation(prob, *cs, variant=2)
+    ref.inject()
+    sim.inject()
+    for tt in (1, 2, 3):
+        ref.step(tt)
+        sim.step(tt)
+        a, b = ref.particles.contents, sim.particles.contents
+        for f in iface.F64_FIELDS:
+            assert np.array_equal(iface.to_host(getattr(a, f), ref.n, np.float64),
+                                  iface.to_host(getattr(b, f), sim.n, np.float64)), (tt, f)
+        for f in iface.I32_FIELDS:
+            assert np.array_equal(iface.to_host(getattr(a, f), ref.n, np.int32),
+                                  iface.to_host(getattr(b, f), sim.n, np.int32)), (tt, f)
+    ref.close()
+    sim.close()
+
+
+def test_two_live_stores_under_lazy_export(iface, make_problem, cs):
+    """The record workspace is shared: stepping a second, larger store must first
+    write the first store's pending state back (round-1 advisor finding)."""
+    small = make_problem("csp", nx=100, nparticles=20000, iterations=2, dt=1.0e-6)
+    big = make_problem("csp", nx=128, nparticles=90000, iterations=2, dt=1.0e-6)
+    want_small = _run(iface, small, cs, 0, 2)
+    want_big = _run(iface, big, cs, 0, 1)
+    iface.set_lazy_export(True)
+    try:
+        a = iface.Simulation(small, *cs, variant=2)
+        b = iface.Simulation(big, *cs, variant=2)
+        a.inject()
+        b.inject()
+        a.step(1)
+        a.step(2)              # pending in the records
+        b.step(1)              # larger store: the workspace is reallocated
+        got_a, got_b = a.particle_arrays(), b.particle_arrays()
+        for f in got_a:
+            assert np.array_equal(got_a[f], want_small[0][f]), f
+            assert np.array_equal(got_b[f], want_big[0][f]), f
+        a.close()
+        b.close()
+    finally:
+        iface.set_lazy_export(False)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_writes_through_the_hooks_reach_the_next_step(iface, make_problem, cs, lazy):
+    """A caller that rewrites particle arrays between steps (here: kills every third
+    particle through neutral_hip_memcpy_h2d) is seen by the tiled variant, whose
+    records would otherwise still hold the old state; neutral_hip_invalidate_particles
+    does the same for writes the library cannot see (here: a torch kernel)."""
+    import torch
+    prob = make_problem("csp", nx=100, nparticles=30000, iterations=3, dt=1.0e-6)
+    kill = np.zeros(30000, dtype=np.int32)
+    kill[::3] = 1
+
+    def through_hook(sim, tt):
+        if tt == 2:
+            iface.library().neutral_hip_memcpy_h2d(
+                C.c_void_p(sim.particles.contents.dead), kill.ctypes.data, kill.nbytes)
+
+    def behind_its_back(sim, tt):
+        if tt == 2:
+            # halve every weight with a copy the library does not see (the HIP
+            # runtime's own hipMemcpy, device to device), and say so
+            n = sim.n
+            weights = iface.to_host(sim.particles.contents.weight, n, np.float64) * 0.5
+            t = torch.from_numpy(weights).to(sim.device)
+            torch.cuda.synchronize()
+            iface.library().neutral_hip_invalidate_particles(sim.particles)
+            hip = _loaded_hip_runtime()
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(C.c_void_p(sim.particles.contents.weight),
+                                 C.c_void_p(t.data_ptr()), n * 8, 3) == 0  # device to device
+
+    iface.set_lazy_export(lazy)
+    try:
+        for between in (through_hook, behind_its_back):
+            want = _run(iface, prob, cs, 0, 3, between=between)
+            got = _run(iface, prob, cs, 2, 3, between=between)
+            _same(want, got)
+            if between is through_hook:
+                assert got[2][1][0] <= 20000
+    finally:
+        iface.set_lazy_export(False)
+
+
+def test_a_table_rewritten_in_place_is_noticed(iface, make_problem, cs):
+    """The view of the tables (identical? bucketed index) is cached across steps and
+    re-checked on the device: halving the absorb table in place between steps must
+    switch the next step to the two-search path, with the right physics."""
+    prob = make_problem("csp", nx=64, nparticles=8192, iterations=3, dt=2.0e-6)
+
+    def rewrite(sim, tt):
+        if tt == 2:
+            sim._av.mul_(0.5)          # values only: same keys, no longer identical
+        if tt == 3:
+            sim._ak.mul_(1.0 + 2**-40)  # keys too: the bucketed index is stale
+            sim._sk.mul_(1.0 + 2**-40)
+
+    want = _run(iface, prob, cs, 0, 3, between=rewrite)
+    got = _run(iface, prob, cs, 2, 3, between=rewrite)
+    _same(want, got)
+    assert [s.same_tables for s in got[3]] == [1, 0, 0]
+    got1 = _run(iface, prob, cs, 1, 3, between=rewrite)
+    _same(want, got1)

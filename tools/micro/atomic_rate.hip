@@ -21,7 +21,9 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
 }
 
 // mode 0: one shared array; mode 1: copy per XCD; mode 2: shared array, neighbouring cells per lane
-// (a particle track: consecutive adds of a lane go to adjacent cells)
+// (a particle track: consecutive adds of a lane go to adjacent cells); mode 3: the flush pattern
+// of an LDS tally window -- the 64 lanes of a wave add to 64 CONSECUTIVE cells (one 512-B row
+// segment per wave instruction), segments at random rows
 template <int kMode>
 __global__ __launch_bounds__(256) void scatter_add(double* tally, unsigned ncells, int iters, unsigned* xcc_seen) {
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,6 +37,10 @@ __global__ __launch_bounds__(256) void scatter_add(double* tally, unsigned ncell
   for (int i = 0; i < iters; ++i) {
     if (kMode == 2) {
       cell = (cell + 1 < ncells) ? cell + 1 : 0;
+    } else if (kMode == 3) {
+      const unsigned wave = tid >> 6;
+      const unsigned seg = hash32(wave * 0x9e3779b9u + (unsigned)i) % (ncells / 64);
+      cell = seg * 64 + (tid & 63);
     } else {
       cell = hash32(cell + 0x9e3779b9u * (unsigned)i + tid) % ncells;
     }
@@ -77,6 +83,7 @@ int main() {
     if (run("shared array, random cells", scatter_add<0>, tally, n, 1, d_seen, blocks, iters)) return 1;
     if (run("copy per XCD, random cells", scatter_add<1>, tally, n, 8, d_seen, blocks, iters)) return 1;
     if (run("shared array, track of cells", scatter_add<2>, tally, n, 1, d_seen, blocks, iters)) return 1;
+    if (run("shared array, 64-cell row segments", scatter_add<3>, tally, n, 1, d_seen, blocks, iters)) return 1;
     CHECK(hipFree(tally));
   }
   return 0;

@@ -131,6 +131,60 @@ __global__ __launch_bounds__(256) void alignbit_kernel(unsigned* out, unsigned s
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;
 }
 
+
+// 32-bit integer VALU of the path (Threefry's xor, carry adds, selects): does the guide's
+// "2 cycles per wave64 instruction with >= 2 waves per SIMD" apply to them, or do they hold
+// the SIMD for 4 cycles like the f64 / 64-bit ones?
+#define U32_KERNEL(NAME, BODY)                                                   \
+  __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed) {    \
+    unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;     \
+    _Pragma("unroll 1") for (int i = 0; i < kIters; ++i) {                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { BODY }                     \
+    }                                                                            \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;              \
+  }
+
+U32_KERNEL(xor32_kernel,
+  asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a0) : "v"(a1));
+  asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a1) : "v"(a2));
+  asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a2) : "v"(a3));
+  asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a3) : "v"(a0));)
+U32_KERNEL(addco32_kernel,
+  asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a0) : "v"(a1) : "vcc");
+  asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a1) : "v"(a2) : "vcc");
+  asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a2) : "v"(a3) : "vcc");
+  asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a3) : "v"(a0) : "vcc");)
+U32_KERNEL(addu32_kernel,
+  asm volatile("v_add_u32 %0, %0, %1" : "+v"(a0) : "v"(a1));
+  asm volatile("v_add_u32 %0, %0, %1" : "+v"(a1) : "v"(a2));
+  asm volatile("v_add_u32 %0, %0, %1" : "+v"(a2) : "v"(a3));
+  asm volatile("v_add_u32 %0, %0, %1" : "+v"(a3) : "v"(a0));)
+U32_KERNEL(cndmask32_kernel,
+  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a0) : "v"(a1) : "vcc");
+  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a1) : "v"(a2) : "vcc");
+  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a2) : "v"(a3) : "vcc");
+  asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a3) : "v"(a0) : "vcc");)
+U32_KERNEL(mov32_kernel,
+  asm volatile("v_mov_b32 %0, %1" : "+v"(a0) : "v"(a1));
+  asm volatile("v_mov_b32 %0, %1" : "+v"(a1) : "v"(a2));
+  asm volatile("v_mov_b32 %0, %1" : "+v"(a2) : "v"(a3));
+  asm volatile("v_mov_b32 %0, %1" : "+v"(a3) : "v"(a0));)
+
+__global__ __launch_bounds__(256) void fma32_kernel(float* out, float seed) {
+  float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+#pragma unroll 1
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a1) : "v"(a2), "v"(a3));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a2) : "v"(a3), "v"(a0));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a3) : "v"(a0), "v"(a1));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
 template <typename K, typename T>
 static int run(const char* name, K kernel, T* out, T seed, double ops_per_thread, int blocks, const char* unit) {
   hipEvent_t e0, e1;
@@ -164,6 +218,12 @@ int main() {
     if (run("rcp f64", rcp64_kernel, (double*)buf, 1.5, kIters * 32.0, blocks, "op")) return 1;
     if (run("add u64", add64i_kernel, (uint64_t*)buf, (uint64_t)3, kIters * 32.0, blocks, "op")) return 1;
     if (run("alignbit b32", alignbit_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_xor_b32", xor32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_add_co_u32", addco32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_add_u32", addu32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_cndmask_b32", cndmask32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_mov_b32", mov32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (run("v_fma_f32", fma32_kernel, (float*)buf, 1.0f, kIters * 32.0, blocks, "op")) return 1;
     if (per_cu == 16) {
       if (run("v_mul_f64", mul64_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "op")) return 1;
       if (run("v_add_f64", add64f_kernel, (double*)buf, 1.0, kIters * 32.0, blocks, "op")) return 1;
