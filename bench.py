@@ -4,18 +4,26 @@
 Workload (BASELINE.json: the metric is quoted on "problems/csp at 400x400,
 1e8 particles"): the csp deck at nx = ny = 400 with 1e8 source particles.  One
 bench "step" is one timestep of solve_transport_2d over every particle (the
-deck runs 10 of them).  With N GPUs the 1e8 particles are split into N
-contiguous id ranges (strong scaling), each rank tallies privately and the
-400x400 f64 tally is all-reduced (RCCL) at the end of every step.
+deck runs 10 of them).  With N GPUs there is one process per GPU; the library
+shards the 1e8 particles into N contiguous id ranges (strong scaling), each rank
+tallies privately and solve_transport_2d ends every step with one all-reduce of
+the 400x400 f64 tally over RCCL (include/neutral_hip.h, "ranks").
 
 Timed region: W untimed warm-up timesteps, then the particles are re-injected
 and the tally zeroed, then exactly K timesteps (master_key 1..K) between barrier +
 torch.cuda.synchronize() pairs; MAX over ranks.  Inputs are resident in HBM
-before the timed region starts.
+before the timed region starts.  `value` is measured the way an unmodified
+main.c drives the library (the SoA particle arrays are current after every
+step); `lazy_export` is a second timed region with neutral_hip_set_lazy_export.
 
 One JSON line on rank 0 (see README "bench contract"), with
-  roofline     algorithmic bytes (SURVEY.md 8(d) model) per
-               launch / mean HIP-event duration of the history kernel
+  roofline     the bound that holds for the dominant kernel -- vector instruction
+               issue: issue cycles per launch (wave-level VALU instructions by class
+               from the committed PMC passes, profiles/pmc_per_event.json, scaled
+               by THIS run's event counts, priced with the measured cycles per class)
+               / mean HIP-event duration of the kernel in this run / SIMD cycles
+               available; next to it the HBM view SURVEY.md 8(d) asks for:
+               algorithmic bytes, the compulsory floor B_hbm_min and measured traffic
   cpu_baseline the CPU oracle timed on this host's cores on a bounded sample of
                the same workload (rank 0, N = 1 only)
   parity_vs_cpu  the HIP path re-run on that same sample: per-cell tally L2
@@ -35,6 +43,17 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# vector issue: 256 CUs x 4 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+# cycles one wave64 instruction holds its SIMD's vector issue, measured per class with
+# tools/micro/valu_peak.hip at 3-4 waves per SIMD (profiles/r02/valu_peak.log):
+#   f64 add/mul/fma, 64-bit integer add, f64 conversions, v_alignbit_b32, v_add_co_u32   4
+#   v_rcp/rsq/sqrt_f64                                                                   16
+#   plain 32-bit ops (v_xor_b32, v_add_u32, v_mov_b32, v_fma_f32)                        2.2-2.4
+# The PMC classes do not separate the 2- from the 4-cycle 32-bit instructions, so the
+# issue cycles of a launch are bracketed: every instruction outside the f64/int64/cvt/
+# transcendental classes priced at 2 cycles (lower bound: `frac`) or at 4 (upper).
+CYCLES_FULL, CYCLES_TRANS, CYCLES_SHORT = 4.0, 16.0, 2.0
 
 WORKLOADS = {
     # name: (deck, nx, nparticles, deck iterations)
@@ -58,102 +77,123 @@ def algorithmic_bytes(histories, facets, collisions, census, same_tables):
             facets * 24 + census * 16)
 
 
-def touched_bytes(kernel, histories, facets, collisions, census):
-    """Global-memory bytes THIS implementation's algorithm touches (not HBM
-    traffic: most of it is served by L1/L2): an 80-B record in and out plus the
-    4-B sort index per history handled, 8 B density, a bucketed cs lookup (two
-    2-B index entries, ~2 key probes, 32 B of bracket keys/values = 52 B) per
-    history and per collision, 32 B of edges per event, 8 B density per facet.
-    Tallies of the streaming kernel go to LDS; the collision kernel's few
-    tallies are 16-B RMWs."""
-    lookup = 52
-    b = histories * (160 + 4 + 8 + lookup) + (facets + collisions + census) * 32 + \
-        collisions * lookup + facets * 8
-    if kernel != "stream_kernel":
-        b += (facets + census) * 16
-    return b
+def hbm_floor_bytes(histories, nx, ny, table_entries):
+    """B_hbm_min of SURVEY.md 8(d): what must cross HBM when everything but the
+    particles is cached -- 152 B of particle state per history, the two tables
+    (keys + values) and the mesh arrays (density, tally) once."""
+    return histories * 152 + 2 * 2 * 8 * table_entries + 2 * 8 * nx * ny
 
 
-def kernel_rooflines(results, same_tables):
-    """Per-kernel (name, mean ms per launch, mean algorithmic bytes per launch)
-    over the timed launches of this rank.  The tiled variant has two history
-    kernels: the streaming kernel handles every history's prologue, its facets
-    and census; the collision kernel resumes the suspended histories."""
-    n = len(results)
+def kernel_events(results):
+    """What each kernel of the tiled pipeline handled over the timed launches of this
+    rank (the library's per-step statistics)."""
     if results[0].stats.variant != 2:
-        b = sum(algorithmic_bytes(r.nprocessed, r.facets, r.collisions, r.census, same_tables)
-                for r in results) / n
         name = "history_kernel" if results[0].stats.variant == 0 else "history_regroup_kernel"
-        return [(name, sum(r.kernel_ms for r in results) / n, b, None)]
-    bs = bc = ts = tc = 0.0
+        return {name: {"histories": sum(r.nprocessed for r in results),
+                       "facets": sum(r.facets for r in results),
+                       "collisions": sum(r.collisions for r in results),
+                       "census": sum(r.census for r in results),
+                       "ms": sum(r.kernel_ms for r in results)}}
+    ev = {"stream_kernel": {"histories": 0, "facets": 0, "collisions": 0, "census": 0, "ms": 0.0},
+          "history_regroup_kernel": {"histories": 0, "facets": 0, "collisions": 0, "census": 0,
+                                     "ms": 0.0}}
     for r in results:
         st = r.stats
-        bs += algorithmic_bytes(r.nprocessed, st.stream_facets, 0, st.stream_census, same_tables)
-        bc += algorithmic_bytes(st.suspended, r.facets - st.stream_facets, r.collisions,
-                                r.census - st.stream_census, same_tables)
-        ts += touched_bytes("stream_kernel", r.nprocessed, st.stream_facets, 0, st.stream_census)
-        tc += touched_bytes("history_regroup_kernel", st.suspended, r.facets - st.stream_facets,
-                            r.collisions, r.census - st.stream_census)
-    return [("stream_kernel", sum(r.stats.stream_ms for r in results) / n, bs / n, ts / n),
-            ("history_regroup_kernel", sum(r.stats.collide_ms for r in results) / n, bc / n,
-             tc / n),
-            ("tile sort (rocPRIM radix sort + 3 small kernels)",
-             sum(r.stats.sort_ms for r in results) / n, 0.0, 0.0)]
+        s, c = ev["stream_kernel"], ev["history_regroup_kernel"]
+        s["histories"] += r.nprocessed
+        s["facets"] += st.stream_facets
+        s["census"] += st.stream_census
+        s["ms"] += st.stream_ms
+        c["histories"] += st.suspended
+        c["facets"] += r.facets - st.stream_facets
+        c["collisions"] += r.collisions
+        c["census"] += r.census - st.stream_census
+        c["ms"] += st.collide_ms
+    return ev
 
 
-def profile_entry(deck, nx, ntotal, variant, kernel):
-    """The committed rocprofv3 PMC figures of `kernel` for this exact configuration
-    (profiles/pmc_traffic.json, made by tools/pmc_traffic.py from separate --pmc
-    passes of this same command), or None when none is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# the event a kernel's instruction and traffic counts scale with
+PRIMARY_EVENT = {"stream_kernel": "facets", "history_regroup_kernel": "collisions",
+                 "history_kernel": "collisions"}
+
+
+def profile_entry(deck, nx, variant, kernel):
+    """The committed rocprofv3 PMC figures of `kernel` for this deck and mesh
+    (profiles/pmc_per_event.json, made by tools/pmc_events.py from separate --pmc
+    passes of this same command): counters PER PRIMARY EVENT of the profiled launches,
+    or None when none is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_per_event.json")
     try:
         with open(path) as f:
             table = json.load(f)
     except OSError:
         return None
     for e in table.get("entries", []):
-        if (e["deck"], e["nx"], e["nparticles"], e["variant"], e["kernel"]) == \
-                (deck, nx, ntotal, variant, kernel):
+        if (e["deck"], e["nx"], e["variant"], e["kernel"]) == (deck, nx, variant, kernel):
             return e
     return None
 
 
-def measured_traffic(deck, nx, ntotal, variant, kernel):
-    """HBM bytes per launch of `kernel` from the FETCH_SIZE / WRITE_SIZE passes."""
-    e = profile_entry(deck, nx, ntotal, variant, kernel)
-    return None if e is None else e["hbm_bytes_per_launch"]
-
-
-# vector issue: one wave64 instruction per SIMD per 4 cycles (16 lanes per cycle),
-# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz.  tools/micro/valu_peak.hip
-# measures 95.7 % of it with f64 FMAs (profiles/r01g/valu_peak.log).
-VALU_PEAK_WAVE_SLOTS = 256 * 4 * 2.4e9 / 4
-
-
-def valu_issue(deck, nx, ntotal, variant, kernel, kernel_ms):
-    """What actually bounds the history kernels: vector
-    instruction issue.  Wave-level VALU instructions per launch from the committed
-    PMC pass; a quarter-rate f64 instruction (rcp/rsq/sqrt) holds the SIMD for four
-    issue slots.  The live launch duration of this run prices them."""
-    e = profile_entry(deck, nx, ntotal, variant, kernel)
-    if e is None or "SQ_INSTS_VALU_per_launch" not in e:
+def issue_roofline(deck, nx, variant, kernel, ev, launches):
+    """Vector-issue roofline of one kernel: issue cycles of THIS run's launches (per-event
+    PMC coefficients x this run's events) over the SIMD cycles its measured duration
+    offers."""
+    e = profile_entry(deck, nx, variant, kernel)
+    n = ev[PRIMARY_EVENT[kernel]]
+    if e is None or n == 0 or ev["ms"] <= 0:
         return None
-    insts = e["SQ_INSTS_VALU_per_launch"]
-    trans = e.get("SQ_INSTS_VALU_TRANS_F64_per_launch", 0.0)
-    slots = insts + 3.0 * trans
-    achieved = slots / (kernel_ms * 1e-3)
-    out = {"kernel": kernel, "wave_valu_insts_per_launch": insts,
-           "quarter_rate_f64_insts_per_launch": trans, "issue_slots_per_launch": slots,
-           "achieved": achieved / 1e9, "peak": VALU_PEAK_WAVE_SLOTS / 1e9,
-           "unit": "G wave-instruction slots/s", "frac": achieved / VALU_PEAK_WAVE_SLOTS,
-           "peak_note": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
-    if e.get("SQ_ACTIVE_INST_VALU_per_launch"):
-        out["lane_utilisation"] = e.get("SQ_THREAD_CYCLES_VALU_per_launch", 0.0) / \
-            (e["SQ_ACTIVE_INST_VALU_per_launch"] * 64.0)
-    if e.get("GRBM_GUI_ACTIVE_per_launch"):
-        # summed over the 8 XCDs; busy cycles / wall time = effective shader clock
-        out["effective_clock_ghz_profiled"] = e["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / \
-            (kernel_ms * 1e-3) / 1e9
+    c = e["per_event"]
+    insts = c["SQ_INSTS_VALU"] * n
+    trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) * n
+    full = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64",
+                                       "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_INT64",
+                                       "SQ_INSTS_VALU_CVT")) * n
+    short = max(0.0, insts - trans - full)
+    lo = CYCLES_FULL * full + CYCLES_TRANS * trans + CYCLES_SHORT * short
+    hi = CYCLES_FULL * (full + short) + CYCLES_TRANS * trans
+    seconds = ev["ms"] * 1e-3
+    avail = SIMD_CYCLES_PER_S * seconds
+    out = {"bound": "valu_issue", "kernel": kernel,
+           "achieved": lo / seconds / 1e9, "peak": SIMD_CYCLES_PER_S / 1e9,
+           "unit": "G SIMD issue cycles/s", "frac": lo / avail,
+           "frac_if_every_32bit_op_took_4_cycles": hi / avail,
+           "kernel_ms_avg": ev["ms"] / launches,
+           "wave_valu_insts_per_launch": insts / launches,
+           "f64_int64_cvt_insts_per_launch": full / launches,
+           "quarter_rate_f64_insts_per_launch": trans / launches,
+           "other_insts_per_launch": short / launches,
+           "valu_insts_per_event": c["SQ_INSTS_VALU"], "event": PRIMARY_EVENT[kernel],
+           "events_per_launch": n / launches,
+           "pricing": "cycles per wave64 instruction: 4 (f64, int64, cvt), 16 (rcp/rsq/sqrt "
+                      "f64), 2 (everything else: lower bound; tools/micro/valu_peak.hip)",
+           "profiled": e.get("source", "profiles/pmc_per_event.json")}
+    if c.get("SQ_ACTIVE_INST_VALU"):
+        out["lane_utilisation"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / \
+            (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_INST_ANY") is not None:
+        out["wait_inst_any_share_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    return out
+
+
+def hbm_view(deck, nx, variant, kernel, ev, launches, same_tables):
+    """The HBM side of one kernel: SURVEY 8(d) algorithmic bytes and, from the
+    FETCH_SIZE / WRITE_SIZE passes, the traffic that actually crossed HBM."""
+    b = algorithmic_bytes(ev["histories"], ev["facets"], ev["collisions"], ev["census"],
+                          same_tables)
+    seconds = ev["ms"] * 1e-3
+    out = {"algorithmic_bytes_per_launch": b / launches,
+           "achieved_gbs_by_algorithmic_bytes": b / seconds / 1e9 if seconds > 0 else None,
+           "note": "algorithmic bytes price every cs lookup at the reference's 15 probes "
+                   "(SURVEY 8d); the bucketed index in LDS removes most of them and the rest "
+                   "is served by L1/L2, so this figure can exceed the HBM peak: it is not a "
+                   "roofline fraction"}
+    e = profile_entry(deck, nx, variant, kernel)
+    n = ev[PRIMARY_EVENT[kernel]]
+    if e is not None and n and "hbm_bytes" in e["per_event"]:
+        traffic = e["per_event"]["hbm_bytes"] * n
+        out["traffic_bytes_per_launch"] = traffic / launches
+        out["traffic_gbs"] = traffic / seconds / 1e9
+        out["traffic_frac_of_hbm_peak"] = traffic / seconds / 1e9 / HBM_PEAK_GBS
     return out
 
 
@@ -190,10 +230,12 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=2,
                     help="0 over-particle, 1 event-regrouped, 2 tiled (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--no-lazy-leg", action="store_true",
+                    help="skip the second timed region (lazy export)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "host"],
+                    help="tally exchange for N > 1: RCCL over xGMI, or staged through the host")
     ap.add_argument("--share-device", action="store_true",
-                    help="testing only: every rank uses GPU 0 (needs --backend gloo)")
+                    help="testing only: every rank uses GPU 0 (needs --comm host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work of the cpu_baseline sample")
     return ap.parse_args()
@@ -255,7 +297,6 @@ def main():
     if args.gpus > 1 and world == 1:
         # not under a launcher: start one (child process; nothing here has touched the GPU)
         port = os.environ.get("MASTER_PORT", "29517")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
@@ -263,7 +304,6 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -272,92 +312,130 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.share_device:
-        if args.backend != "gloo":
-            raise SystemExit("--share-device needs --backend gloo (RCCL wants one GPU per rank)")
+        if args.comm != "host":
+            raise SystemExit("--share-device needs --comm host (RCCL wants one GPU per rank)")
         local_rank = 0
+    if args.comm == "host":
+        os.environ["NEUTRAL_HIP_COMM"] = "host"
+    os.environ.setdefault("NEUTRAL_HIP_QUIET", "1")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: GPU {local_rank} is not visible "
+                         f"({torch.cuda.device_count()} devices)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
 
     from neutral_amd import cs_table, decks, host
     from neutral_amd import interface as iface
-    from neutral_amd.shard import StepTallyExchange, shard_range
+
+    iface.set_device(local_rank)
+    # the rank layer of the library: TCP rendezvous of the ranks (MASTER_ADDR, MASTER_PORT
+    # + 1), then RCCL on this rank's GPU with a time limit; a rank that cannot get RCCL up
+    # makes every rank stage the exchange through the host instead (reported below)
+    transport = iface.comm_start() if world > 1 else iface.COMM_NONE
+    lib = iface.library()
 
     iface.set_quiet(True)
-    # nothing reads the particle arrays between timesteps (main.c with
-    # visit_dump = 0 does not either): the tiled variant keeps them in its
-    # tile-sorted record store and writes the SoA arrays back once, after the run
-    iface.set_lazy_export(True)
     deck, nx, ntotal, deck_its = WORKLOADS[args.workload]
     nx = args.nx or nx
     ntotal = args.nparticles or ntotal
     K, W = args.steps, args.warmup
     keys, values = cs_table.load()
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            lib.neutral_hip_comm_barrier()
+        torch.cuda.synchronize()
+
     with tempfile.TemporaryDirectory() as tmp:
         path = decks.write_deck(deck, os.path.join(tmp, f"{deck}_r{rank}.params"), nx=nx,
                                 ny=nx, nparticles=ntotal, iterations=max(K, 1))
         prob = host.setup_problem(path, decks.ARCH_WIDTH, decks.ARCH_HEIGHT)
-        first, count = shard_range(ntotal, rank, world)
-        sim = iface.Simulation(prob, keys, values, device=local_rank, shard=(first, count),
-                               variant=args.variant)
-        exchange = StepTallyExchange(sim.tally, world)
-        global_tally = sim.tally
+        # shard=None: with several ranks inject_particles cuts this rank's share itself
+        sim = iface.Simulation(prob, keys, values, device=local_rank, variant=args.variant)
 
-        def step(tt):
-            # kernels add into the per-step buffer; one all-reduce per step (N > 1)
-            sim.tally = exchange.begin_step()
-            r = sim.step(tt)
-            exchange.finish_step()
-            sim.tally = global_tally
-            return r
-
-        # ---- warm-up: W untimed timesteps, then restore the injected state ----
-        sim.inject()
-        for tt in range(1, W + 1):
-            step(tt)
-        sim.inject()
-        global_tally.zero_()
-
-        def fence():
+        def timed_region(lazy):
+            """W warm-up steps, re-injection, K timed steps; returns (results, seconds,
+            global event totals, write-back ms)."""
+            iface.set_lazy_export(lazy)
+            sim.inject()
+            for tt in range(1, W + 1):
+                sim.step(tt)
+            sim.inject()
+            sim.tally.zero_()
+            fence()
+            t0 = time.perf_counter()
+            results = [sim.step(tt) for tt in range(1, K + 1)]
+            fence()
+            elapsed = time.perf_counter() - t0
+            t_wb = time.perf_counter()
+            lib.neutral_hip_sync_particles(sim.particles)   # lazy: the deferred write-back
             torch.cuda.synchronize()
+            writeback_ms = 1e3 * (time.perf_counter() - t_wb)
             if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
+                elapsed = lib.neutral_hip_comm_max(elapsed)
+            # (with several ranks the library's event counts are already global sums)
+            tot = {"facets": sum(r.facets for r in results),
+                   "collisions": sum(r.collisions for r in results),
+                   "census": sum(r.census for r in results),
+                   "histories": sum(r.nprocessed for r in results)}
+            return results, elapsed, tot, writeback_ms
 
-        fence()
-        t0 = time.perf_counter()
-        results = [step(tt) for tt in range(1, K + 1)]
-        fence()
-        elapsed = time.perf_counter() - t0
-
+        # ---- the headline: the library as an unmodified main.c drives it ----
+        results, elapsed, tot, _ = timed_region(lazy=False)
         stats = iface.last_step()
-        # the deferred write-back of the SoA particle arrays, timed on its own: what
-        # every step would additionally cost a caller that reads those arrays
-        t_wb = time.perf_counter()
-        iface.library().neutral_hip_sync_particles(sim.particles)
-        torch.cuda.synchronize()
-        writeback_ms = 1e3 * (time.perf_counter() - t_wb)
-        tot = torch.tensor([sum(r.facets for r in results), sum(r.collisions for r in results),
-                            sum(r.census for r in results), sum(r.nprocessed for r in results)],
-                           dtype=torch.float64, device=sim.device)
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=sim.device)
-        if world > 1:
-            dist.all_reduce(tot)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        facets, collisions, census, histories = (int(v) for v in tot.tolist())
-        elapsed = float(tmax.item())
-        particle_steps = facets + collisions + census
+        particle_steps = tot["facets"] + tot["collisions"] + tot["census"]
+        global_tally = float(sim.tally.sum().item())
+        lazy = None
+        if not args.no_lazy_leg:
+            l_results, l_elapsed, l_tot, l_wb = timed_region(lazy=True)
+            iface.set_lazy_export(False)
+            lazy = {"value": (l_tot["facets"] + l_tot["collisions"] + l_tot["census"]) / l_elapsed,
+                    "ms_per_step": 1e3 * l_elapsed / K, "ms_per_writeback_on_demand": l_wb,
+                    "mode": "neutral_hip_set_lazy_export(1): the SoA particle arrays are written "
+                            "back on demand (nothing reads them between timesteps; main.c with "
+                            "visit_dump = 0 does not either), not by every step",
+                    "events_equal": l_tot == tot}
 
         if rank == 0:
-            # roofline of the dominant kernel, from this rank's launches (HIP events
-            # recorded inside the C-ABI on the stream the kernels run on)
-            kernels = kernel_rooflines(results, bool(stats.same_tables))
-            dom = max(kernels, key=lambda k: k[1])
-            achieved = dom[2] / (dom[1] * 1e-3) / 1e9
+            # rooflines from this rank's launches (HIP events recorded inside the C-ABI on
+            # the stream the kernels run on); with several ranks the per-kernel event
+            # counts are this rank's share only for the tiled pipeline's split -- the
+            # library reports global sums there too, so scale by rank count
+            kev = kernel_events(results)
+            for ev in kev.values():
+                for k in ("histories", "facets", "collisions", "census"):
+                    ev[k] = ev[k] / world
+            same = bool(stats.same_tables)
+            variant = int(stats.variant)
+            kernels = []
+            for name, ev in kev.items():
+                kernels.append({"name": name, "ms_per_launch": ev["ms"] / K,
+                                "events_per_launch": {k: ev[k] / K for k in
+                                                      ("histories", "facets", "collisions",
+                                                       "census")},
+                                "valu_issue": issue_roofline(deck, nx, variant, name, ev, K),
+                                "hbm": hbm_view(deck, nx, variant, name, ev, K, same)})
+            if variant == 2:
+                kernels.append({"name": "tile sort (count, scan, place, chunks) + collision queue",
+                                "ms_per_launch": sum(r.stats.sort_ms for r in results) / K})
+            dom = max((k for k in kernels if "valu_issue" in k), key=lambda k: k["ms_per_launch"])
+            histories_rank = tot["histories"] / world
+            floor = hbm_floor_bytes(histories_rank / K, nx, nx, len(keys))
+            traffic = sum((k.get("hbm") or {}).get("traffic_bytes_per_launch", 0.0)
+                          for k in kernels if "hbm" in k)
+            roofline = dict(dom["valu_issue"] or {"bound": "valu_issue", "kernel": dom["name"],
+                                                  "achieved": None, "peak":
+                                                  SIMD_CYCLES_PER_S / 1e9, "frac": None,
+                                                  "unit": "G SIMD issue cycles/s"})
+            roofline["traffic"] = (dom.get("hbm") or {}).get("traffic_bytes_per_launch")
+            roofline["hbm"] = {
+                "dominant_kernel": dom.get("hbm"),
+                "b_hbm_min_per_step": floor,
+                "traffic_per_step": traffic or None,
+                "traffic_over_b_hbm_min": (traffic / floor) if traffic else None,
+                "step_traffic_gbs": (traffic / (elapsed / K) / 1e9) if traffic else None,
+                "peak_gbs": HBM_PEAK_GBS,
+                "hbm_copy_measured_gbs": measured_copy_bandwidth(sim.device)}
             out = {
                 "metric": "particle-steps/sec",
                 "value": particle_steps / elapsed,
@@ -374,40 +452,23 @@ def main():
                                        "400x400, 1e8 particles)",
                            "deck": deck, "nx": nx, "ny": nx, "nparticles": ntotal,
                            "timesteps": K, "parallelism": f"particle-shard x{world}",
-                           "kernel_variant": int(stats.variant)},
+                           "kernel_variant": variant,
+                           "particle_arrays": "current after every step (default ABI)",
+                           "tally_exchange": {iface.COMM_NONE: "none (one rank)",
+                                              iface.COMM_RCCL: "RCCL all-reduce per step",
+                                              iface.COMM_HOST: "staged through the host (TCP)"}
+                           [transport]},
                 "ns_per_particle_step": 1e9 * elapsed / particle_steps,
-                "histories_per_s": histories / elapsed,
-                "events": {"facets": facets, "collisions": collisions, "census": census,
-                           "histories": histories},
-                "global_tally": float(global_tally.sum().item()),
-                "particle_writeback": {
-                    "mode": "deferred (neutral_hip_set_lazy_export): nothing reads the SoA "
-                            "particle arrays between timesteps; written back once after the run",
-                    "ms_per_writeback": writeback_ms,
-                    "value_if_written_back_every_step":
-                        particle_steps / (elapsed + K * writeback_ms * 1e-3)},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": measured_traffic(deck, nx, ntotal, int(stats.variant),
-                                                         dom[0]),
-                             "kernel": dom[0], "kernel_ms_avg": dom[1],
-                             "algorithmic_bytes_per_launch": dom[2],
-                             "note": "algorithmic bytes price each cs lookup at the reference's "
-                                     "15 probes (SURVEY 8d); this implementation's bucketed "
-                                     "index touches far fewer, see own_algorithm",
-                             "own_algorithm": None if dom[3] is None else {
-                                 "touched_bytes_per_launch": dom[3],
-                                 "achieved": dom[3] / (dom[1] * 1e-3) / 1e9,
-                                 "frac": dom[3] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                             "valu_issue": valu_issue(deck, nx, ntotal, int(stats.variant),
-                                                      dom[0], dom[1])},
-                "kernels": [{"name": k[0], "ms_per_launch": k[1],
-                             "algorithmic_bytes_per_launch": k[2],
-                             "touched_bytes_per_launch": k[3],
-                             "valu_issue": valu_issue(deck, nx, ntotal, int(stats.variant),
-                                                      k[0], k[1])} for k in kernels],
+                "histories_per_s": tot["histories"] / elapsed,
+                "events": tot,
+                "global_tally": global_tally,
+                "host_waits_per_step": int(stats.host_syncs),
+                "stream_passes_per_step": int(stats.stream_passes),
+                "tile_cells": int(stats.tile_cells),
+                "lazy_export": lazy,
+                "roofline": roofline,
+                "kernels": kernels,
             }
-            out["roofline"]["hbm_copy_measured_gbs"] = measured_copy_bandwidth(sim.device)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], oracle_run, n_sample = cpu_baseline(deck, nx, K,
                                                                          args.cpu_seconds, tmp)
@@ -435,8 +496,8 @@ def main():
             print(json.dumps(out), flush=True)
         sim.close()  # (idempotent)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        lib.neutral_hip_comm_barrier()
+        lib.neutral_hip_comm_stop()
 
 
 if __name__ == "__main__":

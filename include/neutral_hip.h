@@ -178,6 +178,8 @@ typedef struct {
   int stream_passes_enqueued; /* tiled variant: stream passes enqueued (the last step's
                            count plus one when nothing was waited for in between) */
   int tile_cells;       /* tiled variant: tile edge chosen for the problem (16..128 cells) */
+  double export_ms;     /* tiled variant, default mode: HIP-event time of the write-back of
+                           the records to the SoA arrays (not part of kernel_ms) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */
@@ -215,9 +217,9 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
                                     NeutralHipParticle* particles);
 /* Particle state and the tiled variant.  The tiled variant works on a private
  * array of records sorted by mesh tile that MIRRORS the SoA store of `particles`.
- * By default every kernel that ends a history also writes its final state to the
- * SoA arrays (eleven scattered stores per particle and timestep), so the arrays are
- * current whenever solve_transport_2d returns, as the reference's are.  In the other
+ * By default solve_transport_2d ends with a pass that writes the records back to the
+ * SoA arrays (a permutation of 76 B per particle: 11 ms at 1e8 particles), so the
+ * arrays are current whenever it returns, as the reference's are.  In the other
  * direction the arrays are read when the store is first stepped and after anything
  * the library can see rewriting them: inject/reinject, and writes through its own
  * hooks (copy_buffer, copy_int_buffer, neutral_hip_memcpy_h2d, neutral_hip_memset)
@@ -225,7 +227,7 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
  * library's back (its own kernels, hipMemcpy) must say so with
  * neutral_hip_invalidate_particles() before the next solve_transport_2d; the next
  * step then re-imports the arrays (one pass over the store).
- * lazy != 0 drops the per-history stores: the arrays are written back only by
+ * lazy != 0 drops that pass: the arrays are written back only by
  * neutral_hip_sync_particles() (or a call that needs them: another variant, reinject,
  * a read through the hooks, free): use it when nothing reads the arrays between
  * timesteps, as main.c with visit_dump = 0 (main.c:91-94,149-152).
@@ -236,6 +238,58 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
 void neutral_hip_set_lazy_export(int lazy);
 void neutral_hip_sync_particles(NeutralHipParticle* particles);
 void neutral_hip_invalidate_particles(NeutralHipParticle* particles);
+/* ---- ranks: one process per GPU on one node ------------------------------------
+ * The reference leaves rank and rank count to the parent project's initialise_mpi
+ * (main.c:62) and calls barrier() (main.c:75,112) and reduce_all_sum
+ * (omp3/neutral.c:530); its own MPI code is compiled out (neutral_data.h:10-14).
+ * Here ranks are processes started by a launcher that exports RANK, WORLD_SIZE,
+ * LOCAL_RANK, MASTER_ADDR, MASTER_PORT (torchrun's convention; `neutral.hip --gpus
+ * N` forks them itself).  Particles are sharded over the ranks in contiguous id
+ * ranges, the mesh is replicated, and solve_transport_2d ends every timestep with
+ * ONE all-reduce of that step's tally contributions (sum, f64, nx*ny) over RCCL /
+ * xGMI, after which energy_deposition_tally holds the same global mesh on every
+ * rank -- all behind the unchanged three functions:
+ *   inject_particles(nparticles = N, ...)  creates this rank's shard of the N
+ *       particles (global ids first..first+count-1 as RNG keys);
+ *   solve_transport_2d(...)                steps the shard it finds in `particles`
+ *       (*nlocal_particles is not rewritten), all-reduces tally and event counters;
+ *   validate(...)                          sums the (already global) tally.
+ * The unchanged main.c gets there through the host layer linked into this library:
+ * initialise_mpi reads the environment, initialise_devices binds the rank to GPU
+ * LOCAL_RANK and calls neutral_hip_comm_start(). */
+enum {
+  NEUTRAL_HIP_COMM_NONE = 0, /* one rank */
+  NEUTRAL_HIP_COMM_RCCL = 1, /* ncclAllReduce on the kernels' stream */
+  NEUTRAL_HIP_COMM_HOST = 2  /* staged through the host over TCP (RCCL unavailable, or
+                                NEUTRAL_HIP_COMM=host: ranks sharing a GPU in tests) */
+};
+/* Joins the ranks (TCP rendezvous at MASTER_ADDR:NEUTRAL_COMM_PORT, default
+ * MASTER_PORT + 1), then brings up RCCL on the current device (select it first) with
+ * a time limit (NEUTRAL_COMM_TIMEOUT seconds, default 120).  Returns the transport in
+ * use (NEUTRAL_HIP_COMM_*).  Idempotent. */
+int neutral_hip_comm_start(void);
+void neutral_hip_comm_stop(void);
+int neutral_hip_comm_rank(void);
+int neutral_hip_comm_nranks(void);
+int neutral_hip_comm_transport(void);
+/* sharding by inject_particles when there are several ranks (default 1); 0 leaves the
+ * id range to the caller (neutral_hip_set_pid_base + its own particle count) */
+void neutral_hip_set_auto_shard(int on);
+/* particles in a sharded store created by inject_particles (this rank's share);
+ * -1 for a store that was not sharded (one rank, or auto-shard off) */
+int neutral_hip_store_count(const NeutralHipParticle* particles);
+/* in-place sum over the ranks of n doubles in [device] memory, on hip_stream */
+void neutral_hip_comm_allreduce_f64(double* device_buf, size_t n, void* hip_stream);
+/* max over the ranks of a host scalar; barrier of the ranks (host side) */
+double neutral_hip_comm_max(double v);
+void neutral_hip_comm_barrier(void);
+/* used by the host layer: bind this rank to its GPU and start the rank layer;
+ * finish the device's work (the device half of barrier()) */
+void neutral_hip_bind_rank_device(int local_rank);
+void neutral_hip_comm_barrier_device(void);
+/* one-rank RCCL check on the current device: 0 ok, 1 librccl not loadable, 2 failure */
+int neutral_hip_comm_selftest(int n);
+
 /* Frees a store created by inject_particles. */
 void neutral_hip_free_particles(NeutralHipParticle* particles);
 /* Raw copies for callers without a HIP runtime of their own (ctypes, C). */

@@ -13,7 +13,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "neutral_comm.h"
 #include "neutral_kernels.h"
+
+extern "C" {
+#include "../host/comms.h"
+}
 
 extern "C" {
 /* host layer (neutral_amd/host/host.c), linked into this library */
@@ -83,6 +88,7 @@ struct State {
   neutral::StepCounters* d_counters = nullptr;
   int* d_flag = nullptr;
   unsigned long long* d_check = nullptr;            /* 4 words of tables_check_kernel */
+  neutral::ParticleView* d_export_view = nullptr;   /* the stepped store's array pointers */
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   unsigned short* d_index_fine = nullptr;           /* finer index of the collision stage */
   hipEvent_t ev_start = nullptr;
@@ -90,6 +96,7 @@ struct State {
   hipEvent_t ev_sorted = nullptr;   /* tiled variant: after the sort */
   hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   hipEvent_t ev_collected = nullptr; /* tiled variant: after the collision queue is built */
+  hipEvent_t ev_exported = nullptr; /* tiled variant: after the write-back to the SoA arrays */
   TableView tables;
   /* workspace of the tiled variant, grown on demand */
   neutral::TiledArgs tiled = {};
@@ -105,6 +112,18 @@ struct State {
   int plan_passes = 0;
   long long plan_queue = -1;
   int host_syncs = 0;              /* waits for the device inside the current call */
+  /* ranks: particle stores made by inject_particles (this rank's shards) and the
+   * per-step tally that is all-reduced before it joins the caller's mesh */
+  int auto_shard = 1;
+  struct Store {
+    const void* key; /* particles->x */
+    int count;
+    uint64_t first;
+  };
+  Store stores[16] = {};
+  int nstores = 0;
+  double* d_step_tally = nullptr;
+  size_t step_tally_cells = 0;
   /* mesh extent: only for the tiled variant's "facets still ahead" estimate */
   double mesh_width = 1.0;
   double mesh_height = 1.0;
@@ -128,6 +147,7 @@ void ensure_scratch() {
   HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
   HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
   HIP_CHECK(hipMalloc((void**)&g.d_check, 4 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
   g.tables.valid = false; /* its indexes live in the other device's scratch */
   HIP_CHECK(hipMalloc((void**)&g.d_index_fine,
                       sizeof(unsigned short) * (kMaxFineIndexBuckets + 1)));
@@ -139,6 +159,7 @@ void ensure_scratch() {
   HIP_CHECK(hipEventCreate(&g.ev_sorted));
   HIP_CHECK(hipEventCreate(&g.ev_streamed));
   HIP_CHECK(hipEventCreate(&g.ev_collected));
+  HIP_CHECK(hipEventCreate(&g.ev_exported));
   g.scratch_device = dev;
 }
 
@@ -393,6 +414,72 @@ neutral::ParticleView view_of(const NeutralHipParticle* p) {
   return v;
 }
 
+/* true on every rank when the condition holds on any (one rank: the condition itself) */
+bool any_rank(bool mine) {
+  if (neutral::comm_nranks() == 1) {
+    return mine;
+  }
+  uint64_t v = mine ? 1u : 0u;
+  comms_allreduce_u64(&v, 1, COMMS_MAX);
+  return v != 0;
+}
+
+__global__ void add_step_tally_kernel(double* __restrict__ tally, const double* __restrict__ step,
+                                      size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    tally[i] += step[i];
+  }
+}
+
+/* End of a timestep with several ranks: ONE all-reduce of the step's tally
+ * contributions (sum, f64, nx*ny) on the kernels' stream; the sum joins the caller's
+ * mesh, which then holds the same global tally on every rank.  The step buffer is
+ * cleared again, so a step that needs more stream passes than were enqueued simply
+ * exchanges what those add. */
+void exchange_step(const neutral::SolveArgs& a, double* tally) {
+  const size_t ncells = (size_t)a.nx * (size_t)a.ny;
+  neutral::comm_allreduce_sum(a.tally, ncells, true, g.stream);
+  hipLaunchKernelGGL(add_step_tally_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
+                     g.stream, tally, (const double*)a.tally, ncells);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemsetAsync(a.tally, 0, sizeof(double) * ncells, g.stream));
+}
+
+const State::Store* find_store(const NeutralHipParticle* p) {
+  for (int i = 0; i < g.nstores; ++i) {
+    if (p && g.stores[i].key == (const void*)p->x) {
+      return &g.stores[i];
+    }
+  }
+  return nullptr;
+}
+
+void remember_store(const NeutralHipParticle* p, int count, uint64_t first) {
+  const int slot = (g.nstores < 16) ? g.nstores++ : 15; /* (the oldest entries win) */
+  g.stores[slot] = State::Store{(const void*)p->x, count, first};
+}
+
+void forget_store(const NeutralHipParticle* p) {
+  for (int i = 0; i < g.nstores; ++i) {
+    if (g.stores[i].key == (const void*)p->x) {
+      g.stores[i] = g.stores[--g.nstores];
+      return;
+    }
+  }
+}
+
+/* this step's tally contributions when several ranks share the problem */
+double* step_tally(size_t ncells) {
+  if (ncells > g.step_tally_cells) {
+    if (g.d_step_tally) HIP_CHECK(hipFree(g.d_step_tally));
+    HIP_CHECK(hipMalloc((void**)&g.d_step_tally, sizeof(double) * ncells));
+    g.step_tally_cells = ncells;
+  }
+  HIP_CHECK(hipMemsetAsync(g.d_step_tally, 0, sizeof(double) * ncells, g.stream));
+  return g.d_step_tally;
+}
+
 void run_inject(const int nparticles, const int local_nx, const int local_ny, const int pad,
                 const double left_off, const double bottom_off, const double width,
                 const double height, const int x_off, const int y_off, const double dt,
@@ -482,8 +569,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.y_off = y_off;
   a.dt = dt;
   a.inv_ntotal_particles = 1.0 / (double)ntotal_particles; /* omp3/neutral.c:120 */
-  a.nparticles = *nlocal_particles;
-  a.pid_base = g.pid_base;
+  /* several ranks: the store holds this rank's shard (inject_particles made it so) */
+  const State::Store* shard = (neutral::comm_nranks() > 1) ? find_store(particles) : nullptr;
+  a.nparticles = shard ? shard->count : *nlocal_particles;
+  a.pid_base = shard ? shard->first : g.pid_base;
   a.p = view_of(particles);
   a.density = density;
   a.edgex = edgex;
@@ -499,7 +588,16 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.tiles_x = 0;
   a.tile_shift = 4;
   a.susp = nullptr;
-  a.export_soa = (tiled && !g.lazy_export) ? 1 : 0;
+  /* Default (eager) mode: the SoA arrays are current when the call returns.  One
+   * export pass at the end of the step does that (11 ms at 1e8 particles); letting
+   * every kernel that ends a history store it to the arrays itself -- eleven
+   * scattered 8-byte stores per history -- costs 18 ms (profiles/r02: fused export)
+   * and stays an experiment: NEUTRAL_HIP_FUSED_EXPORT=1. */
+  const char* fused_env = getenv("NEUTRAL_HIP_FUSED_EXPORT");
+  const bool fused_export = tiled && !g.lazy_export && fused_env && atoi(fused_env) != 0;
+  const bool pass_export = tiled && !g.lazy_export && !fused_export;
+  a.export_soa = fused_export ? 1 : 0;
+  a.export_view = nullptr;
   a.abort_flag = (const int*)g.d_check; /* low word of tables_check_kernel's verdict */
 
   if (tiled) {
@@ -532,6 +630,12 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       g.extent_edges = (const void*)edgex;
       g.extent_nx = nx;
       g.extent_ny = ny;
+    }
+    if (a.export_soa) {
+      /* the kernels read the store's array pointers from memory where a history ends */
+      HIP_CHECK(hipMemcpyAsync(g.d_export_view, &a.p, sizeof(a.p), hipMemcpyHostToDevice,
+                               g.stream));
+      a.export_view = g.d_export_view;
     }
     g.tiled.cells_per_x = (double)nx / g.mesh_width;
     g.tiled.cells_per_y = (double)ny / g.mesh_height;
@@ -589,22 +693,38 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
 
     HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
+    const bool exchange = neutral::comm_nranks() > 1;
+    if (exchange) {
+      a.tally = step_tally((size_t)nx * (size_t)ny);
+    }
     HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
     if (tiled) {
+      /* Stream passes are enqueued on what the last step needed (plus one, which
+       * finds nothing to do when the guess holds) without waiting in between; the
+       * first step of a problem starts with two.  The collision stage's occupancy
+       * follows the last step's queue length. */
       neutral::TiledPlan plan;
-      plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 0;
+      plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 2;
       plan.blocks_per_cu =
           g.plan_queue >= 0
               ? neutral::tiled_collision_blocks_per_cu((unsigned)g.plan_queue, device_cus())
-              : -1;
+              : 0;
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, plan, 0, g.ev_sorted,
-                                            g.ev_streamed, g.ev_collected, &passes,
-                                            &g.host_syncs));
+                                            g.ev_streamed, g.ev_collected, &passes));
     } else {
       HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
     }
     HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+    if (pass_export) {
+      /* this step's records (t.rec_out until the swap below) to the SoA arrays */
+      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.order, a.p, a.nparticles,
+                                               g.stream));
+    }
+    HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
 
+    if (exchange) {
+      exchange_step(a, energy_deposition_tally);
+    }
     /* the one wait of a steady-state step: counters, the pipeline's control words
      * and the verdict on the table view */
     unsigned long long check[4] = {0, 0, 0, 0};
@@ -614,7 +734,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
     }
     wait_for_stream();
-    if (check[0] == 0) {
+    /* (several ranks take every decision that leads to another exchange together:
+     * the collectives must pair up) */
+    if (!any_rank(check[0] != 0)) {
       break;
     }
     if (attempt >= 2) {
@@ -627,21 +749,25 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   unsigned long long queue_total = ctrl[2];
   if (tiled) {
     /* migrants left over: the step outran the plan (it needs more stream passes than
-     * the last one did).  Finish it pass by pass; the newly suspended histories get
-     * a collision stage of their own (the first one's are marked done). */
-    while (ctrl[4] != 0) {
-      neutral::TiledPlan more = {0, -1};
+     * the last one did).  More passes, as many again as have run; the histories they
+     * suspend get a collision stage of their own (the first one's are marked done),
+     * and with several ranks their tallies an exchange of their own. */
+    while (any_rank(ctrl[4] != 0)) {
+      neutral::TiledPlan more = {passes < 2 ? 2 : passes, 0};
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
-                                            g.ev_streamed, g.ev_collected, &passes,
-                                            &g.host_syncs));
+                                            g.ev_streamed, g.ev_collected, &passes));
       HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
-      neutral::StepCounters again[2];
-      HIP_CHECK(hipMemcpyAsync(again, g.d_counters, sizeof(again), hipMemcpyDeviceToHost,
-                               g.stream));
+      if (pass_export) {
+        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.order, a.p,
+                                                 a.nparticles, g.stream));
+      }
+      HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
+      if (neutral::comm_nranks() > 1) {
+        exchange_step(a, energy_deposition_tally);
+      }
+      HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
       HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
       wait_for_stream();
-      hc[0] = again[0];
-      hc[1] = again[1];
       queue_total += ctrl[2];
     }
     /* this step's records become the next step's input */
@@ -653,14 +779,14 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     t.info_in = t.info_out;
     t.info_out = swap_info;
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
-    g.plan_queue = (long long)queue_total;
-    /* eager mode: the kernels that ended a history wrote it to the SoA store */
-    g.soa_valid = a.export_soa ? true : false;
+    g.plan_queue = (long long)queue_total; /* (this rank's own queue) */
+    g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
   }
 
   float ms = 0.0f;
   HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
-  float ms_sort = 0.0f, ms_stream = 0.0f, ms_collide = ms;
+  float ms_sort = 0.0f, ms_stream = 0.0f, ms_collide = ms, ms_export = 0.0f;
+  HIP_CHECK(hipEventElapsedTime(&ms_export, g.ev_stop, g.ev_exported));
   if (tiled) {
     /* sort_ms: the first sort and the queue build (later sorts sit inside stream_ms) */
     float ms_collect = 0.0f;
@@ -671,6 +797,17 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     ms_sort += ms_collect;
   }
 
+  if (neutral::comm_nranks() > 1) {
+    /* event counters of all ranks (a handful of words: over the host links) */
+    static_assert(sizeof(hc) % 8 == 0, "StepCounters is summed word by word");
+    const unsigned aborted[2] = {hc[0].aborted, hc[1].aborted};
+    comms_allreduce_u64((uint64_t*)hc, sizeof(hc) / 8, COMMS_SUM);
+    hc[0].aborted = aborted[0]; /* (two 32-bit fields share a word: keep the local ones) */
+    hc[1].aborted = aborted[1];
+    uint64_t q = queue_total;
+    comms_allreduce_u64(&q, 1, COMMS_SUM);
+    queue_total = q;
+  }
   neutral::StepCounters h = hc[0];
   h.nprocessed += hc[1].nprocessed;
   h.nfacets += hc[1].nfacets;
@@ -704,6 +841,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.host_syncs = g.host_syncs;
   g.last.stream_passes_enqueued = tiled ? passes : 0;
   g.last.tile_cells = tiled ? (1 << g.tiled.tile_shift) : 0;
+  g.last.export_ms = (double)ms_export;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */
@@ -725,7 +863,18 @@ size_t inject_particles(const int nparticles, const int global_nx, const int loc
     fprintf(stderr, "Could not allocate particle array.\n"); /* omp3/neutral.c:571-573 */
     exit(EXIT_FAILURE);
   }
-  const size_t n = (size_t)(nparticles > 0 ? nparticles : 0);
+  /* several ranks: this rank's contiguous share of the ids 0..nparticles-1 (the
+   * OpenMP static split of omp3/neutral.c:64-74 over ranks); ids stay global, so
+   * every history is the one a single rank would run */
+  int local = nparticles > 0 ? nparticles : 0;
+  const bool sharded = neutral::comm_nranks() > 1 && g.auto_shard;
+  if (sharded) {
+    long long first = 0, count = 0;
+    comms_shard_range(local, neutral::comm_rank(), neutral::comm_nranks(), &first, &count);
+    g.pid_base = (uint64_t)first;
+    local = (int)count;
+  }
+  const size_t n = (size_t)local;
   size_t allocation = 0;
   double** f64[] = {&p->x,      &p->y,      &p->omega_x,      &p->omega_y,
                     &p->energy, &p->weight, &p->dt_to_census, &p->mfp_to_collision};
@@ -739,8 +888,11 @@ size_t inject_particles(const int nparticles, const int global_nx, const int loc
     allocation += sizeof(int) * n;
   }
   *particles = p;
+  if (sharded) {
+    remember_store(p, local, g.pid_base);
+  }
 
-  run_inject(nparticles, local_nx, local_ny, pad, local_particle_left_off,
+  run_inject(local, local_nx, local_ny, pad, local_particle_left_off,
              local_particle_bottom_off, local_particle_width, local_particle_height, x_off,
              y_off, dt, edgex, edgey, initial_energy, p);
   return allocation;
@@ -904,7 +1056,11 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
                                     const int y_off, const double dt, const double* edgex,
                                     const double* edgey, const double initial_energy,
                                     NeutralHipParticle* particles) {
-  run_inject(nparticles, local_nx, local_ny, pad, local_particle_left_off,
+  const State::Store* st = find_store(particles);
+  if (st) {
+    g.pid_base = st->first; /* this rank's shard, whatever count the caller names */
+  }
+  run_inject(st ? st->count : nparticles, local_nx, local_ny, pad, local_particle_left_off,
              local_particle_bottom_off, local_particle_width, local_particle_height, x_off,
              y_off, dt, edgex, edgey, initial_energy, particles);
 }
@@ -925,10 +1081,18 @@ void neutral_hip_invalidate_particles(NeutralHipParticle* particles) {
   }
 }
 
+void neutral_hip_set_auto_shard(int on) { g.auto_shard = on ? 1 : 0; }
+
+int neutral_hip_store_count(const NeutralHipParticle* particles) {
+  const State::Store* st = find_store(particles);
+  return st ? st->count : -1;
+}
+
 void neutral_hip_free_particles(NeutralHipParticle* p) {
   if (!p) {
     return;
   }
+  forget_store(p);
   if (g.rec_owner == (const void*)p->x) {
     g.rec_owner = nullptr; /* pending state dies with the store */
     drop_records();

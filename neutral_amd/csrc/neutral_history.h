@@ -344,18 +344,23 @@ __device__ __forceinline__ void load_particle(History& h, const SolveArgs& a, in
   h.id = (unsigned)pid;
 }
 
+__device__ __forceinline__ void store_particle_view(const History& h, const ParticleView& p,
+                                                    int pid) {
+  p.x[pid] = h.x;
+  p.y[pid] = h.y;
+  p.omega_x[pid] = h.omega_x;
+  p.omega_y[pid] = h.omega_y;
+  p.energy[pid] = h.energy;
+  p.weight[pid] = h.weight;
+  p.dt_to_census[pid] = h.dt_to_census;
+  p.mfp_to_collision[pid] = h.mfp_to_collision;
+  p.cellx[pid] = h.cellx;
+  p.celly[pid] = h.celly;
+  p.dead[pid] = h.dead;
+}
+
 __device__ __forceinline__ void store_particle(const History& h, const SolveArgs& a, int pid) {
-  a.p.x[pid] = h.x;
-  a.p.y[pid] = h.y;
-  a.p.omega_x[pid] = h.omega_x;
-  a.p.omega_y[pid] = h.omega_y;
-  a.p.energy[pid] = h.energy;
-  a.p.weight[pid] = h.weight;
-  a.p.dt_to_census[pid] = h.dt_to_census;
-  a.p.mfp_to_collision[pid] = h.mfp_to_collision;
-  a.p.cellx[pid] = h.cellx;
-  a.p.celly[pid] = h.celly;
-  a.p.dead[pid] = h.dead;
+  store_particle_view(h, a.p, pid);
 }
 
 __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r) {

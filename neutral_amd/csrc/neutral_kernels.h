@@ -130,6 +130,9 @@ struct SolveArgs {
    * `p` at its id, so the interface's arrays are current when solve_transport_2d
    * returns (0: lazy export, the records are written back on demand) */
   int export_soa;
+  /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
+   * eleven more array pointers (the collision stage): read where a history ends */
+  const ParticleView* export_view;
   /* [device] non-zero: the host's cached view of the cs tables (identity, bucketed
    * indexes) no longer matches the tables; history kernels return at once and the
    * host re-runs the step with a fresh view (null: no cached view in use) */
@@ -173,12 +176,11 @@ struct TiledArgs {
   int max_chunks;
 };
 
-/* what the host knows before it enqueues a timestep of the tiled pipeline */
+/* what the host enqueues of a timestep of the tiled pipeline in one go */
 struct TiledPlan {
-  int stream_passes; /* > 0: enqueue this many stream passes back to back (last step's
-                        count plus one); 0: look at the migrant counter after every pass */
-  int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit);
-                        < 0: read the queue length first (a host synchronisation) */
+  int stream_passes; /* stream passes to enqueue back to back (steady state: what the
+                        last step needed plus one) */
+  int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit) */
 };
 
 enum Variant {
@@ -217,19 +219,20 @@ int tiled_window_min_particles(int tile_shift);
 void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
                     int* max_chunks);
 int tiled_collision_blocks_per_cu(unsigned queued, int cus);
-/* Enqueues stream passes first_pass.. (plan), the collision queue and the collision
- * stage.  a.counters must point at TWO StepCounters records: [0] streaming kernel,
- * [1] collision kernel.  The optional events are recorded after the first sort,
- * after the last enqueued streaming pass and after the collision queue is built.
- * With plan.stream_passes > 0 and plan.blocks_per_cu >= 0 nothing here waits for the
- * device: the caller reads t.ctrl (migrants left over, passes used, queue length)
- * with the step's counters and calls again with first_pass = *passes_enqueued if
- * migrants are left.  This step's records are t.rec_out / t.info_out (the caller
- * swaps in/out when the step is complete).  *host_syncs is incremented per wait. */
+/* Enqueues plan.stream_passes stream passes starting with pass number first_pass, the
+ * collision queue and the collision stage; nothing here waits for the device.
+ * a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]
+ * collision kernel.  The optional events are recorded after the first sort, after
+ * the last enqueued streaming pass and after the collision queue is built.  The
+ * caller reads t.ctrl (migrants left over, passes used, queue length) with the
+ * step's counters and calls again with first_pass = *passes_enqueued while migrants
+ * are left (histories suspended by the later passes get a collision stage of their
+ * own; the earlier ones are marked done).  This step's records are t.rec_out /
+ * t.info_out: the caller swaps in/out when the step is complete. */
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
                               const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
                               hipEvent_t after_stream, hipEvent_t after_collect,
-                              int* passes_enqueued, int* host_syncs);
+                              int* passes_enqueued);
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

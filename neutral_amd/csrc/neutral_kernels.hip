@@ -248,8 +248,13 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
     store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
-    if (a.export_soa) {
-      store_particle(h, a, (int)h.id); /* the interface's arrays stay current */
+    if (a.export_view) {
+      /* the interface's arrays stay current.  The eleven array pointers are fetched
+       * here, from memory: as kernel arguments they would be live through the
+       * collision loop and push it into scratch (100 B per lane, -20 %) */
+      const ParticleView* pv = a.export_view;
+      asm volatile("" : "+s"(pv)); /* (not foldable back into the kernel arguments) */
+      store_particle_view(h, *pv, (int)h.id);
     }
   } else {
     store_particle(h, a, pid);
@@ -820,9 +825,17 @@ static int resident_blocks(K kernel, size_t lds) {
   if (hipGetDevice(&dev) == hipSuccess) {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds) != hipSuccess ||
+  /* registers decide (3 waves per SIMD: section above); the occupancy query is asked
+   * without the dynamic LDS, which it prices against 64 KB per CU where gfx950 has
+   * 160 KB, and the LDS bound is applied by hand */
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
       per_cu < 1) {
-    per_cu = 1;
+    per_cu = 2;
+  }
+  if (lds > 0) {
+    const int by_lds = (int)((size_t)(160 * 1024) / lds);
+    per_cu = (by_lds < per_cu) ? by_lds : per_cu;
+    per_cu = (per_cu < 1) ? 1 : per_cu;
   }
   return cus * per_cu;
 }

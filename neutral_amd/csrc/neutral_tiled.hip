@@ -97,7 +97,18 @@ enum Ctrl : int {
   kCtrlActive = 3,
   kCtrlMigrants = 4,   /* histories the last stream pass handed to the next one */
   kCtrlPassesUsed = 5, /* stream passes of this step that had work */
+  kCtrlWindowed = 6,   /* chunks of this pass that stream under an LDS window */
 };
+/* A history of a chunk WITHOUT a window (a sparse tile, the small tail of a dense one)
+ * runs on global atomics.  When other chunks of the pass do have windows it is handed
+ * to the next pass after this many facet crossings (about one window's worth), like a
+ * history that left its window: the next sort may put it into a tile that is worth a
+ * window, and no pass has to wait for a lone history that crosses thousands of cells
+ * (the reference's stream deck as shipped: 7 000 facets per history and step). */
+#ifndef NEUTRAL_UNWINDOWED_BUDGET
+#define NEUTRAL_UNWINDOWED_BUDGET 160
+#endif
+constexpr unsigned kUnwindowedBudget = NEUTRAL_UNWINDOWED_BUDGET;
 /* a history leaves its window for another pass only if about this many facet
  * crossings still lie ahead; shorter tails finish with global atomics */
 #ifndef NEUTRAL_MIGRATE_MIN_FACETS
@@ -192,6 +203,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
     __syncthreads();
     s_part[tid] += c0;
     __syncthreads();
+  }
+  if (tid == 0) {
+    t.ctrl[kCtrlWindowed] = 0; /* tile_chunks_kernel counts this pass's windowed chunks */
   }
   unsigned run = s_part[tid] - sum; /* exclusive */
   for (int i = lo; i < hi; ++i) {
@@ -399,19 +413,27 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   /* sweep 1 counts this range's chunks, sweep 2 (after the scan) writes them */
   unsigned nch = 0;
   unsigned chunk = 0;
+  unsigned nwindowed = 0;
   for (int sweep = 0; sweep < 2; ++sweep) {
     unsigned run_begin = 0, run_end = 0; /* pending run of sparse tiles: [begin, end) */
     auto emit = [&](unsigned begin, unsigned end, unsigned tile, unsigned windowed) {
-      for (unsigned b = begin; b < end; b += cp) {
-        const unsigned e = (b + cp < end) ? b + cp : end;
+      if (end <= begin) {
+        return;
+      }
+      /* equal parts (a tile of chunk_particles + 200 becomes two halves, not a full
+       * chunk and a tail too small for a window) */
+      const unsigned parts = (end - begin + cp - 1) / cp;
+      const unsigned size = (end - begin + parts - 1) / parts;
+      for (unsigned b = begin; b < end; b += size) {
+        const unsigned e = (b + size < end) ? b + size : end;
         if (sweep == 0) {
           nch++;
         } else {
+          const unsigned w = (windowed && (e - b) >= (unsigned)t.window_min_particles) ? 1u : 0u;
           if (chunk < (unsigned)t.max_chunks) {
-            /* the last chunk of a dense tile may be too small for a window */
-            t.chunks[chunk] = make_uint4(b, e, tile,
-                                         (windowed && (e - b) >= (unsigned)t.window_min_particles) ? 1u : 0u);
+            t.chunks[chunk] = make_uint4(b, e, tile, w);
           }
+          nwindowed += w;
           chunk++;
         }
       }
@@ -442,6 +464,9 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
       }
       chunk = s_chunks[tid] - nch; /* exclusive */
     }
+  }
+  if (nwindowed) {
+    atomicAdd(&t.ctrl[kCtrlWindowed], nwindowed); /* (zeroed by tile_scan_kernel) */
   }
   if (tid == 1023) {
     t.ctrl[kCtrlNumChunks] = s_chunks[1023];
@@ -511,6 +536,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   }
 
   const int nchunks = (int)t.ctrl[kCtrlNumChunks];
+  /* histories without a window move on after a window's worth of facets when the
+   * pass has windows to offer (wave-uniform) */
+  const bool budget_on = t.allow_migrate && t.ctrl[kCtrlWindowed] != 0;
   int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
   int win_ox = 0;
   int win_oy = 0;
@@ -657,6 +685,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
            * dozen scalar instructions) */
           nfacets += (unsigned)crossed;
           h.nevents += (unsigned)crossed;
+          if (!windowed && budget_on && h.ev == kEvFacet && h.nevents >= kUnwindowedBudget) {
+            /* (h.nevents counts from the load of this pass: prologue and resume zero it) */
+            const double ahead = h.speed * h.dt_to_census;
+            if (ahead * (fabs(h.omega_x) * t.cells_per_x + fabs(h.omega_y) * t.cells_per_y) >
+                kMigrateMinFacets) {
+              park = kRecMigrate;
+            }
+          }
           if (h.nevents > kMaxEventsPerHistory && h.ev == kEvFacet) {
             atomicAdd(&a.counters->aborted, 1u);
             h.ev = kEvEnd; /* ended like a history whose time has run out, next pass */
@@ -669,8 +705,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           store_record(h, a, t.rec_out[pid], kRecIdle);
           t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
                                          t.tile_shift);
-          if (a.export_soa) {
-            store_particle(h, a, (int)h.id); /* the interface's arrays stay current */
+          if (a.export_view) {
+            /* the interface's arrays stay current (pointers fetched here, not kept
+             * in registers through the facet loop) */
+            const ParticleView* pv = a.export_view;
+            asm volatile("" : "+s"(pv));
+            store_particle_view(h, *pv, (int)h.id);
           }
           has = false;
           did_census = (h.ev == kEvCensus);
@@ -827,7 +867,7 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
                               const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
                               hipEvent_t after_stream, hipEvent_t after_collect,
-                              int* passes_enqueued, int* host_syncs) {
+                              int* passes_enqueued) {
   if (passes_enqueued) {
     *passes_enqueued = first_pass;
   }
@@ -850,39 +890,14 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
 
+  /* plan.stream_passes passes, back to back: nothing here waits for the device (the
+   * caller reads the migrant counter with the step's counters and comes back for
+   * more if the step outran the plan) */
   int pass = first_pass;
-  if (plan.stream_passes > 0 && first_pass == 0) {
-    /* steady state: as many passes as the last step needed plus one, without looking
-     * at the migrant counter in between (the caller reads it once, at the end) */
-    for (; pass < plan.stream_passes && pass < kMaxStreamPasses; ++pass) {
-      const hipError_t err = enqueue_stream_pass(a, t, pass, cus, lds, stream, after_sort);
-      if (err != hipSuccess) {
-        return err;
-      }
-    }
-  } else {
-    /* first step of a problem, or a step that outran the plan: one look per pass */
-    for (; pass < kMaxStreamPasses;) {
-      hipError_t err = enqueue_stream_pass(a, t, pass, cus, lds, stream, after_sort);
-      if (err != hipSuccess) {
-        return err;
-      }
-      ++pass;
-      unsigned migrants = 0;
-      err = hipMemcpyAsync(&migrants, &t.ctrl[kCtrlMigrants], sizeof(unsigned),
-                           hipMemcpyDeviceToHost, stream);
-      if (err == hipSuccess) {
-        err = hipStreamSynchronize(stream);
-      }
-      if (err != hipSuccess) {
-        return err;
-      }
-      if (host_syncs) {
-        ++*host_syncs;
-      }
-      if (migrants == 0) {
-        break;
-      }
+  for (int k = 0; k < plan.stream_passes && pass < kMaxStreamPasses; ++k, ++pass) {
+    const hipError_t err = enqueue_stream_pass(a, t, pass, cus, lds, stream, after_sort);
+    if (err != hipSuccess) {
+      return err;
     }
   }
   if (passes_enqueued) {
@@ -901,21 +916,6 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   SolveArgs c = a;
   c.blocks_per_cu = plan.blocks_per_cu;
-  if (plan.blocks_per_cu < 0) {
-    unsigned queued = 0;
-    hipError_t qe = hipMemcpyAsync(&queued, &t.ctrl[kCtrlCollideCount], sizeof(unsigned),
-                                   hipMemcpyDeviceToHost, stream);
-    if (qe == hipSuccess) {
-      qe = hipStreamSynchronize(stream);
-    }
-    if (qe != hipSuccess) {
-      return qe;
-    }
-    if (host_syncs) {
-      ++*host_syncs;
-    }
-    c.blocks_per_cu = tiled_collision_blocks_per_cu(queued, cus);
-  }
   {
     const char* force = getenv("NEUTRAL_K2_BLOCKS_PER_CU"); /* experiment knob */
     if (force) {

@@ -1,7 +1,9 @@
 /*
  * comms.h -- rank-level communication surface (main.c:62,64,70-71,75,112;
- * omp3/neutral.c:530).  The reference runs single-rank (main.c:42-43, MPI
- * blocks are `#if 0`: neutral_data.h:10-14), so these are the one-rank forms.
+ * omp3/neutral.c:530).  The reference ships single-rank (main.c:42-43, MPI blocks
+ * are `#if 0`: neutral_data.h:10-14) but leaves rank and rank count to
+ * initialise_mpi (main.c:62): this layer runs one process per GPU on one node,
+ * particles sharded over the ranks, the mesh replicated (comms_ranks.c).
  */
 #ifndef NEUTRAL_AMD_HOST_COMMS_H
 #define NEUTRAL_AMD_HOST_COMMS_H
@@ -13,7 +15,26 @@
 extern "C" {
 #endif
 
+/* rank and rank count from the launcher's environment (RANK, WORLD_SIZE, LOCAL_RANK,
+ * MASTER_ADDR, MASTER_PORT); one rank when they are absent */
 void initialise_mpi(int argc, char** argv, int* rank, int* nranks);
+
+/* the rank layer itself (comms_ranks.c) */
+enum { COMMS_SUM, COMMS_MIN, COMMS_MAX };
+void comms_start_from_env(void); /* idempotent; rank 0 listens, the others connect */
+void comms_stop(void);
+int comms_rank(void);
+int comms_nranks(void);
+int comms_local_rank(void);
+/* contiguous particle-id range of a rank (the OpenMP static split of
+ * omp3/neutral.c:64-74 over ranks) */
+void comms_shard_range(long long total, int rank, int nranks, long long* first,
+                       long long* count);
+void comms_bcast_bytes(void* buf, size_t n); /* from rank 0 */
+/* element-wise over the ranks, result everywhere, same bits everywhere (host arrays) */
+void comms_allreduce_f64(double* buf, size_t n, int op);
+void comms_allreduce_u64(uint64_t* buf, size_t n, int op);
+void comms_barrier(void);
 void initialise_comms(Mesh* mesh);
 void finalise_comms(void);
 void barrier(void);

@@ -1,0 +1,238 @@
+/*
+ * comms_ranks.c -- the rank layer behind comms.h: one process per GPU on one
+ * node, as the reference's initialise_mpi / barrier / reduce_all_sum call sites
+ * expect of the parent project's MPI layer (main.c:62,75,112; omp3/neutral.c:530)
+ * -- without MPI, which this stack does not have.
+ *
+ * Ranks are ordinary processes started by any launcher that exports
+ * RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun's
+ * convention; `neutral.hip --gpus N` forks them itself).  They meet over TCP:
+ * rank 0 listens on MASTER_ADDR:NEUTRAL_COMM_PORT (default MASTER_PORT + 1), every
+ * other rank connects and names itself; the sockets stay open and carry
+ *   - the host-side collectives of comms.h (barrier, reduce_all_sum/min/max),
+ *   - a broadcast of opaque bytes from rank 0 (the RCCL unique id),
+ *   - an all-reduce of host arrays (star through rank 0, summed in rank order, so
+ *     every rank gets the same bits): the transport of the tally exchange when
+ *     RCCL is not usable (ranks sharing one GPU in tests, a failed RCCL start-up).
+ * The mesh tallies themselves travel over RCCL/xGMI (csrc/neutral_comm.hip).
+ */
+#include "comms.h"
+
+#include <arpa/inet.h>
+#include <errno.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+
+static int g_rank = 0;
+static int g_nranks = 1;
+static int g_local_rank = 0;
+static int g_started = 0;
+static int* g_peer = NULL; /* rank 0: socket of every other rank; others: [0] = rank 0 */
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1.0e-9 * (double)ts.tv_nsec;
+}
+
+static void send_all(int fd, const void* buf, size_t n) {
+  const char* p = (const char*)buf;
+  while (n) {
+    const ssize_t k = send(fd, p, n, MSG_NOSIGNAL);
+    if (k <= 0) {
+      if (k < 0 && errno == EINTR) continue;
+      TERMINATE("rank %d: lost the connection to a peer while sending (%s).\n", g_rank,
+                strerror(errno));
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+}
+
+static void recv_all(int fd, void* buf, size_t n) {
+  char* p = (char*)buf;
+  while (n) {
+    const ssize_t k = recv(fd, p, n, 0);
+    if (k <= 0) {
+      if (k < 0 && errno == EINTR) continue;
+      TERMINATE("rank %d: lost the connection to a peer while receiving (%s).\n", g_rank,
+                k == 0 ? "closed" : strerror(errno));
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+}
+
+static int env_int(const char* name, int fallback) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : fallback;
+}
+
+int comms_rank(void) { return g_rank; }
+int comms_nranks(void) { return g_nranks; }
+int comms_local_rank(void) { return g_local_rank; }
+
+void comms_shard_range(long long total, int rank, int nranks, long long* first,
+                       long long* count) {
+  /* contiguous id ranges, the first total % nranks ranks one longer: the OpenMP
+   * static split of omp3/neutral.c:64-74 over ranks */
+  const long long per = total / nranks;
+  const long long rem = total % nranks;
+  *first = (long long)rank * per + (rank < rem ? rank : rem);
+  *count = per + (rank < rem ? 1 : 0);
+}
+
+void comms_start_from_env(void) {
+  if (g_started) {
+    return;
+  }
+  g_started = 1;
+  g_nranks = env_int("WORLD_SIZE", 1);
+  g_rank = env_int("RANK", 0);
+  g_local_rank = env_int("LOCAL_RANK", g_rank);
+  if (g_nranks < 1 || g_rank < 0 || g_rank >= g_nranks) {
+    TERMINATE("RANK=%d / WORLD_SIZE=%d make no sense.\n", g_rank, g_nranks);
+  }
+  if (g_nranks == 1) {
+    return;
+  }
+  const char* addr = getenv("MASTER_ADDR");
+  if (!addr || !*addr) {
+    addr = "127.0.0.1";
+  }
+  const int port = env_int("NEUTRAL_COMM_PORT", env_int("MASTER_PORT", 29500) + 1);
+  const double deadline = now_s() + (double)env_int("NEUTRAL_COMM_TIMEOUT", 120);
+  struct sockaddr_in sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((unsigned short)port);
+  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) {
+    TERMINATE("MASTER_ADDR=%s is not an IPv4 address (one node: use 127.0.0.1).\n", addr);
+  }
+  const int one = 1;
+  g_peer = (int*)calloc((size_t)g_nranks, sizeof(int));
+  if (g_rank == 0) {
+    const int ls = socket(AF_INET, SOCK_STREAM, 0);
+    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (ls < 0 || bind(ls, (struct sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, g_nranks) != 0) {
+      TERMINATE("rank 0 cannot listen on %s:%d (%s); set NEUTRAL_COMM_PORT.\n", addr, port,
+                strerror(errno));
+    }
+    struct timeval tv = {1, 0};
+    setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    for (int joined = 1; joined < g_nranks;) {
+      const int fd = accept(ls, NULL, NULL);
+      if (fd < 0) {
+        if (now_s() > deadline) {
+          TERMINATE("rank 0: only %d of %d ranks arrived at %s:%d.\n", joined, g_nranks, addr,
+                    port);
+        }
+        continue;
+      }
+      setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      int who = -1;
+      recv_all(fd, &who, sizeof(who));
+      if (who < 1 || who >= g_nranks || g_peer[who]) {
+        TERMINATE("rank 0: a peer announced itself as rank %d of %d.\n", who, g_nranks);
+      }
+      g_peer[who] = fd;
+      joined++;
+    }
+    close(ls);
+  } else {
+    int fd = -1;
+    for (;;) {
+      fd = socket(AF_INET, SOCK_STREAM, 0);
+      if (fd >= 0 && connect(fd, (struct sockaddr*)&sa, sizeof(sa)) == 0) {
+        break;
+      }
+      if (fd >= 0) close(fd);
+      if (now_s() > deadline) {
+        TERMINATE("rank %d cannot reach rank 0 at %s:%d (%s).\n", g_rank, addr, port,
+                  strerror(errno));
+      }
+      usleep(20000);
+    }
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    send_all(fd, &g_rank, sizeof(g_rank));
+    g_peer[0] = fd;
+  }
+  comms_barrier(); /* everybody is connected before anybody goes on */
+}
+
+void comms_stop(void) {
+  if (g_peer) {
+    for (int r = 0; r < g_nranks; ++r) {
+      if (g_peer[r] > 0) close(g_peer[r]);
+    }
+    free(g_peer);
+    g_peer = NULL;
+  }
+  g_started = 0;
+  g_rank = 0;
+  g_nranks = 1;
+}
+
+void comms_bcast_bytes(void* buf, size_t n) {
+  if (g_nranks == 1) {
+    return;
+  }
+  if (g_rank == 0) {
+    for (int r = 1; r < g_nranks; ++r) send_all(g_peer[r], buf, n);
+  } else {
+    recv_all(g_peer[0], buf, n);
+  }
+}
+
+/* element-wise reduction of n 8-byte words over the ranks, result on every rank.
+ * Star through rank 0, combined in rank order: deterministic, and identical bits
+ * everywhere. */
+static void allreduce_words(void* buf, size_t n, int is_f64, int op) {
+  if (g_nranks == 1 || n == 0) {
+    return;
+  }
+  const size_t bytes = n * 8;
+  if (g_rank == 0) {
+    void* in = malloc(bytes);
+    if (!in) {
+      TERMINATE("rank 0: no memory for a %zu-byte reduction buffer.\n", bytes);
+    }
+    for (int r = 1; r < g_nranks; ++r) {
+      recv_all(g_peer[r], in, bytes);
+      if (is_f64) {
+        double* a = (double*)buf;
+        const double* b = (const double*)in;
+        for (size_t i = 0; i < n; ++i) {
+          a[i] = (op == COMMS_SUM) ? a[i] + b[i]
+                                   : (op == COMMS_MIN) ? (b[i] < a[i] ? b[i] : a[i])
+                                                       : (b[i] > a[i] ? b[i] : a[i]);
+        }
+      } else {
+        uint64_t* a = (uint64_t*)buf;
+        const uint64_t* b = (const uint64_t*)in;
+        for (size_t i = 0; i < n; ++i) {
+          a[i] = (op == COMMS_SUM) ? a[i] + b[i]
+                                   : (op == COMMS_MIN) ? (b[i] < a[i] ? b[i] : a[i])
+                                                       : (b[i] > a[i] ? b[i] : a[i]);
+        }
+      }
+    }
+    free(in);
+    for (int r = 1; r < g_nranks; ++r) send_all(g_peer[r], buf, bytes);
+  } else {
+    send_all(g_peer[0], buf, bytes);
+    recv_all(g_peer[0], buf, bytes);
+  }
+}
+
+void comms_allreduce_f64(double* buf, size_t n, int op) { allreduce_words(buf, n, 1, op); }
+void comms_allreduce_u64(uint64_t* buf, size_t n, int op) { allreduce_words(buf, n, 0, op); }
+
+void comms_barrier(void) {
+  uint64_t token = 1;
+  allreduce_words(&token, 1, 0, COMMS_SUM);
+}

@@ -214,14 +214,26 @@ int get_key_value_parameter(const char* specifier, const char* filename,
 void initialise_mpi(int argc, char** argv, int* rank, int* nranks) {
   (void)argc;
   (void)argv;
-  *rank = MASTER;
-  *nranks = 1;
+  comms_start_from_env();
+  *rank = comms_rank();
+  *nranks = comms_nranks();
 }
 
-void initialise_devices(int rank) { (void)rank; }
+/* binds the rank to its GPU when a device kernel set is linked (weak: the
+ * host-memory flavour of the library has no devices) */
+void neutral_hip_bind_rank_device(int local_rank) __attribute__((weak));
+void neutral_hip_comm_barrier_device(void) __attribute__((weak));
+
+void initialise_devices(int rank) {
+  (void)rank;
+  if (neutral_hip_bind_rank_device) {
+    neutral_hip_bind_rank_device(comms_local_rank());
+  }
+}
 
 void initialise_comms(Mesh* mesh) {
-  /* one rank owns the whole mesh: no offsets, every neighbour is the edge */
+  /* every rank owns the whole mesh (particles are sharded, not cells): no offsets,
+   * every neighbour is the edge */
   for (int ii = 0; ii < NNEIGHBOURS; ++ii) {
     mesh->neighbours[ii] = EDGE;
   }
@@ -229,11 +241,28 @@ void initialise_comms(Mesh* mesh) {
   mesh->y_off = 0;
 }
 
-void finalise_comms(void) {}
-void barrier(void) {}
-double reduce_all_sum(double local_val) { return local_val; }
-double reduce_all_min(double local_val) { return local_val; }
-double reduce_all_max(double local_val) { return local_val; }
+void finalise_comms(void) { comms_stop(); }
+
+void barrier(void) {
+  /* main.c:75,112: "everybody has finished the step"; the device's work is part of it */
+  if (neutral_hip_comm_barrier_device) {
+    neutral_hip_comm_barrier_device();
+  }
+  comms_barrier();
+}
+
+double reduce_all_sum(double local_val) {
+  comms_allreduce_f64(&local_val, 1, COMMS_SUM);
+  return local_val;
+}
+double reduce_all_min(double local_val) {
+  comms_allreduce_f64(&local_val, 1, COMMS_MIN);
+  return local_val;
+}
+double reduce_all_max(double local_val) {
+  comms_allreduce_f64(&local_val, 1, COMMS_MAX);
+  return local_val;
+}
 
 void handle_boundary_2d(const int nx, const int ny, Mesh* mesh, double* arr,
                         const int invert, const int pack) {

@@ -8,16 +8,26 @@
  * line.  Everything numerical happens behind the C ABI (include/neutral_hip.h).
  *
  *   neutral.hip <deck.params> [--set key=value ...] [--arch-params FILE]
- *               [--cs-dir DIR] [--tests FILE] [--variant 0|1|2]
+ *               [--cs-dir DIR] [--tests FILE] [--variant 0|1|2] [--gpus N]
+ *
+ * --gpus N runs N ranks, one per GPU of this node: the driver forks them before
+ * anything touches a GPU (ranks are ordinary processes that find each other through
+ * RANK / WORLD_SIZE / MASTER_PORT, so any launcher that exports those -- torchrun
+ * --no-python, for one -- does as well); particles are sharded, every rank holds
+ * the mesh, and each timestep ends with one all-reduce of the tally (RCCL).
  *
  * --set overrides a scalar deck entry (nx, ny, nparticles, iterations, dt,
  * initial_energy): the BASELINE configurations are the shipped decks at other
  * sizes.  ../arch.params (neutral_data.h:32) supplies width/height/sim_end when
  * present; otherwise 1.0 x 1.0, the extent the reference's known answers need.
  */
+#include <arpa/inet.h>
+#include <netinet/in.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -74,12 +84,66 @@ static void write_patched_deck(const char* deck, const char* out, int n, char ke
   fclose(fp);
 }
 
+/* a TCP port nobody listens on right now (for the ranks' rendezvous) */
+static int free_port(void) {
+  const int fd = socket(AF_INET, SOCK_STREAM, 0);
+  struct sockaddr_in sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sin_family = AF_INET;
+  sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  socklen_t len = sizeof(sa);
+  int port = 29611;
+  if (fd >= 0 && bind(fd, (struct sockaddr*)&sa, sizeof(sa)) == 0 &&
+      getsockname(fd, (struct sockaddr*)&sa, &len) == 0) {
+    port = ntohs(sa.sin_port);
+  }
+  if (fd >= 0) close(fd);
+  return port;
+}
+
+/* --gpus N: becomes rank 0..N-1 in N child processes (returns in the children with
+ * the rank's environment set); the parent waits for them and exits with the worst
+ * status.  Called before anything initialises a GPU. */
+static void fork_ranks(int nranks) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "%d", free_port());
+  setenv("MASTER_ADDR", "127.0.0.1", 1);
+  setenv("MASTER_PORT", buf, 1);
+  snprintf(buf, sizeof(buf), "%d", nranks);
+  setenv("WORLD_SIZE", buf, 1);
+  pid_t kids[64];
+  for (int r = 0; r < nranks; ++r) {
+    fflush(stdout);
+    const pid_t pid = fork();
+    if (pid < 0) {
+      TERMINATE("Could not start rank %d.\n", r);
+    }
+    if (pid == 0) {
+      snprintf(buf, sizeof(buf), "%d", r);
+      setenv("RANK", buf, 1);
+      setenv("LOCAL_RANK", buf, 1);
+      return;
+    }
+    kids[r] = pid;
+  }
+  int worst = 0;
+  for (int r = 0; r < nranks; ++r) {
+    int status = 0;
+    waitpid(kids[r], &status, 0);
+    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + WTERMSIG(status);
+    worst = (code > worst) ? code : worst;
+  }
+  exit(worst);
+}
+
 static void load_table(const char* path, NeutralHipCrossSection* cs) {
   const int n = neutral_cs_file_entries(path);
   if (n < 0) {
     TERMINATE("Could not open the cross section file: %s\n", path);
   }
-  printf("File %s contains %d entries\n", path, n); /* neutral_data.c:139 */
+  if (comms_rank() == MASTER) {
+    printf("File %s contains %d entries\n", path, n); /* neutral_data.c:139 */
+  }
   double* h_keys;
   double* h_values;
   allocate_host_data(&h_keys, (size_t)n);
@@ -100,6 +164,19 @@ int main(int argc, char** argv) {
   char keys[MAX_OVERRIDES][64];
   char values[MAX_OVERRIDES][64];
   int noverrides = 0;
+  /* multi-process GPU work on this stack needs dmabuf IPC; read by the runtime at start-up */
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+  for (int i = 2; i + 1 < argc; ++i) {
+    if (strcmp(argv[i], "--gpus") == 0) {
+      const int n = atoi(argv[i + 1]);
+      if (n < 1 || n > 64) {
+        TERMINATE("--gpus wants 1..64\n");
+      }
+      if (n > 1 && !getenv("RANK")) {
+        fork_ranks(n);
+      }
+    }
+  }
   for (int i = 2; i < argc; ++i) {
     if (strcmp(argv[i], "--set") == 0 && i + 1 < argc && noverrides < MAX_OVERRIDES) {
       char* eq = strchr(argv[++i], '=');
@@ -115,6 +192,8 @@ int main(int argc, char** argv) {
       cs_dir = argv[++i];
     } else if (strcmp(argv[i], "--tests") == 0 && i + 1 < argc) {
       neutral_hip_set_tests_file(argv[++i]);
+    } else if (strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) {
+      ++i; /* handled above, before anything touched a GPU */
     } else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc) {
       if (neutral_hip_set_variant(atoi(argv[++i]))) {
         TERMINATE("unknown --variant\n");
@@ -124,7 +203,7 @@ int main(int argc, char** argv) {
     }
   }
 
-  /* deck actually read: the original, or a patched copy */
+  /* deck actually read: the original, or a patched copy (one per rank) */
   char patched[4096];
   const char* read_deck = deck;
   if (noverrides) {
@@ -152,12 +231,16 @@ int main(int argc, char** argv) {
   mesh.nranks = 1;
   mesh.ndims = 2;
 
-  printf("Starting up on %d MI355X-class device(s), kernel set: libneutral_hip (gfx950).\n",
-         neutral_hip_device_count());
-  printf("Loading problem from %s.\n", deck);
-
   initialise_mpi(argc, argv, &mesh.rank, &mesh.nranks);
-  initialise_devices(mesh.rank);
+  const int master = (mesh.rank == MASTER);
+  if (master) {
+    printf("Starting up with %d rank(s), one per GPU, kernel set: libneutral_hip (gfx950).\n",
+           mesh.nranks);
+    printf("Loading problem from %s.\n", deck);
+  } else {
+    neutral_hip_set_quiet(1); /* one "Particles" line per step: rank 0's */
+  }
+  initialise_devices(mesh.rank); /* binds the rank to its GPU, starts the tally exchange */
   initialise_comms(&mesh);
   initialise_mesh_2d(&mesh);
   SharedData shared_data = {0};
@@ -194,7 +277,9 @@ int main(int argc, char** argv) {
                                    src.local_particle_height, mesh.x_off, mesh.y_off, mesh.dt,
                                    mesh.edgex, mesh.edgey, src.initial_energy, &particles);
   }
-  printf("Allocated %.4fGB of data.\n", allocation / GB); /* neutral_data.c:117 */
+  if (master) {
+    printf("Allocated %.4fGB of data.\n", allocation / GB); /* neutral_data.c:117 */
+  }
 
   NeutralHipCrossSection cs_scatter, cs_absorb;
   char path[4096];
@@ -209,7 +294,9 @@ int main(int argc, char** argv) {
   double elapsed_sim_time = 0.0;
   int tt;
   for (tt = 1; tt <= mesh.niters; ++tt) {
-    printf("\nIteration  %d\n", tt);
+    if (master) {
+      printf("\nIteration  %d\n", tt); /* main.c:87-89 */
+    }
     uint64_t facet_events = 0;
     uint64_t collision_events = 0;
     const double t0 = now_seconds();
@@ -221,29 +308,38 @@ int main(int argc, char** argv) {
     barrier();
     const double step_time = now_seconds() - t0;
     wallclock += step_time;
-    printf("Step time  %.4fs\n", step_time);
-    printf("Wallclock  %.4fs\n", wallclock);
-    printf("Facets     %llu\n", (unsigned long long)facet_events);
-    printf("Collisions %llu\n", (unsigned long long)collision_events);
-    printf("Facet Events / s %.2e\n", facet_events / step_time);
-    printf("Collision Events / s %.2e\n", collision_events / step_time);
-    NeutralHipStepStats st;
-    neutral_hip_last_step(&st);
-    printf("Particle-steps / s %.3e (facets + collisions + census, kernels %.2f ms)\n",
-           (double)(st.facets + st.collisions + st.census) / step_time, st.kernel_ms);
+    if (master) {
+      /* (event counts are the sums over all ranks) */
+      printf("Step time  %.4fs\n", step_time);
+      printf("Wallclock  %.4fs\n", wallclock);
+      printf("Facets     %llu\n", (unsigned long long)facet_events);
+      printf("Collisions %llu\n", (unsigned long long)collision_events);
+      printf("Facet Events / s %.2e\n", facet_events / step_time);
+      printf("Collision Events / s %.2e\n", collision_events / step_time);
+      NeutralHipStepStats st;
+      neutral_hip_last_step(&st);
+      printf("Particle-steps / s %.3e (facets + collisions + census, kernels %.2f ms)\n",
+             (double)(st.facets + st.collisions + st.census) / step_time, st.kernel_ms);
+    }
     elapsed_sim_time += mesh.dt;
     if (elapsed_sim_time >= mesh.sim_end) {
-      printf("Reached end of simulation time\n");
+      if (master) {
+        printf("Reached end of simulation time\n");
+      }
       break;
     }
   }
 
   neutral_hip_sync_particles(particles);
   validate(nx, ny, deck, mesh.rank, tally);
-  printf("Final Wallclock %.9fs\n", wallclock);
-  printf("Elapsed Simulation Time %.6fs\n", elapsed_sim_time);
+  if (master) {
+    printf("Final Wallclock %.9fs\n", wallclock);
+    printf("Elapsed Simulation Time %.6fs\n", elapsed_sim_time);
+  }
   if (noverrides) {
     remove(patched);
   }
+  barrier();
+  neutral_hip_comm_stop();
   return 0;
 }

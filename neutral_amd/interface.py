@@ -66,7 +66,7 @@ class StepStats(C.Structure):
                 ("aborted", C.c_uint64), ("stream_passes", C.c_int),
                 ("requeued", C.c_uint64), ("collide_passes", C.c_uint64),
                 ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
-                ("tile_cells", C.c_int)]
+                ("tile_cells", C.c_int), ("export_ms", C.c_double)]
 
 
 # every symbol include/neutral_hip.h declares
@@ -82,6 +82,11 @@ ABI_SYMBOLS = (
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
     "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
     "neutral_hip_invalidate_particles",
+    "neutral_hip_comm_start", "neutral_hip_comm_stop", "neutral_hip_comm_rank",
+    "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_set_auto_shard",
+    "neutral_hip_store_count", "neutral_hip_comm_allreduce_f64", "neutral_hip_comm_max",
+    "neutral_hip_comm_barrier", "neutral_hip_bind_rank_device",
+    "neutral_hip_comm_barrier_device", "neutral_hip_comm_selftest",
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
@@ -124,6 +129,21 @@ _lib.neutral_hip_free_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_set_lazy_export.argtypes = [C.c_int]
 _lib.neutral_hip_sync_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_invalidate_particles.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_comm_start.restype = C.c_int
+_lib.neutral_hip_comm_rank.restype = C.c_int
+_lib.neutral_hip_comm_nranks.restype = C.c_int
+_lib.neutral_hip_comm_transport.restype = C.c_int
+_lib.neutral_hip_set_auto_shard.argtypes = [C.c_int]
+_lib.neutral_hip_store_count.restype = C.c_int
+_lib.neutral_hip_store_count.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+_lib.neutral_hip_comm_max.restype = C.c_double
+_lib.neutral_hip_comm_max.argtypes = [C.c_double]
+_lib.neutral_hip_bind_rank_device.argtypes = [C.c_int]
+_lib.neutral_hip_comm_selftest.restype = C.c_int
+_lib.neutral_hip_comm_selftest.argtypes = [C.c_int]
+
+COMM_NONE, COMM_RCCL, COMM_HOST = 0, 1, 2
 _lib.neutral_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 _lib.neutral_hip_memset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -212,6 +232,12 @@ def set_tests_file(path: str) -> None:
 
 def set_lazy_export(lazy: bool) -> None:
     _lib.neutral_hip_set_lazy_export(1 if lazy else 0)
+
+
+def comm_start() -> int:
+    """Joins the ranks named by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* and brings up
+    the tally exchange on the current device; returns COMM_NONE / COMM_RCCL / COMM_HOST."""
+    return _lib.neutral_hip_comm_start()
 
 
 def last_step() -> StepStats:
@@ -329,8 +355,12 @@ class Simulation:
         self.variant = variant
         if variant is not None:
             set_variant(variant)
+        # shard = (first, count): this process owns those global ids (the caller shards);
+        # None: all of them -- or, when the rank layer is up (comm_start) with several
+        # ranks, the share inject_particles cuts for this rank
         first, count = shard if shard is not None else (0, problem.nparticles)
         self.pid_base, self.n = int(first), int(count)
+        self.explicit_shard = shard is not None
 
         def dev(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
@@ -362,10 +392,16 @@ class Simulation:
     def inject(self):
         """inject_particles on first use, a state reset (no allocation) afterwards."""
         set_pid_base(self.pid_base)
+        _lib.neutral_hip_set_auto_shard(0 if self.explicit_shard else 1)
         if self.particles is None:
             p = self.p
             self.particles, self.bytes_allocated = inject_particles(
                 self.n, p.nx, *self._inject_args())
+            local = _lib.neutral_hip_store_count(self.particles)
+            if local >= 0:  # the library cut this rank's share
+                self.n = local
+                self.pid_base = int(_lib.neutral_hip_get_pid_base())
+                self.nlocal = C.c_int(self.n)
         else:
             _lib.neutral_hip_reinject_particles(self.n, *self._inject_args(), self.particles)
 

@@ -1,11 +1,21 @@
 """Pins the CPU oracle (oracle/neutral_oracle.c) to the reference.
 
-* Threefry2x64-20: bit for bit against the reference's own Random123 header
-  compiled in place (oracle/_ref) and against the vectors in SURVEY.md 8(c);
-* cross-section lookup: against the survey's recorded values;
-* the whole history loop: against the event counts / tallies of the reference's
-  omp3 backend recorded in BASELINE.md section 2 (exact integers), and against
-  problems/neutral.tests (reference's own known answers, 1e-3).
+Two kinds of pin, kept apart by test name so a reader sees which is which:
+
+REFERENCE-HELD (test_reference_held__*): what the reference tree itself holds or
+what can be built from it here without stand-ins --
+* Threefry2x64-20 bit for bit against the reference's own Random123 header compiled
+  in place (oracle/_ref);
+* the whole history loop against problems/neutral.tests:1-3 at the decks' default
+  sizes (the reference's own known answers, tolerance 1e-3, neutral_data.h:27) --
+  all three decks, in the default CPU suite.
+
+RECORDED, NOT REPRODUCIBLE HERE (test_recorded_not_reproducible_here__*): numbers
+the survey wrote down (SURVEY.md sections 4, 6, 8c) from an
+omp3 binary it built against stand-ins for the absent parent project's headers.
+That build is not in this repository and by the rules pins nothing; the numbers are
+kept as a regression record -- exact integer event counts, tallies to 1e-13 -- which
+the oracle reproduces digit for digit.
 """
 import os
 
@@ -20,14 +30,14 @@ def _h(x):
     return int(x, 16)
 
 
-def test_threefry_known_answers(pins):
+def test_recorded_not_reproducible_here__threefry_vectors(pins):
     for v in pins["threefry2x64_20"]:
         out = ob.threefry(_h(v["ctr"][0]), _h(v["ctr"][1]), _h(v["key"][0]), _h(v["key"][1]))
         assert out == (_h(v["out"][0]), _h(v["out"][1]))
 
 
 @pytest.mark.skipif(not ob.have_ref_threefry(), reason="oracle/_ref not built")
-def test_threefry_matches_reference_random123(pins):
+def test_reference_held__threefry_matches_reference_random123(pins):
     # the recorded vectors really are what the reference header produces ...
     for v in pins["threefry2x64_20"]:
         out = ob.ref_threefry(_h(v["ctr"][0]), _h(v["ctr"][1]), _h(v["key"][0]), _h(v["key"][1]))
@@ -54,7 +64,7 @@ def test_random_numbers_unit_interval():
     assert 0.45 < flat.mean() < 0.55
 
 
-def test_cs_lookup_known_answers(pins, cs):
+def test_recorded_not_reproducible_here__cs_lookup_values(pins, cs):
     table = ob.CsTable(*cs)
     for e in pins["cs_lookup"]:
         value, index = table.lookup(e["energy"])
@@ -101,7 +111,7 @@ def _run_oracle(make_problem, cs, name, nx, nparticles, iterations):
 
 
 @pytest.mark.parametrize("i", range(5))
-def test_oracle_reproduces_recorded_omp3_runs(pins, make_problem, cs, i):
+def test_recorded_not_reproducible_here__omp3_runs(pins, make_problem, cs, i):
     r = pins["omp3_runs"][i]
     run, facets, collisions, last = _run_oracle(make_problem, cs, r["deck"], r["nx"],
                                                 r["nparticles"], r["iterations"])
@@ -116,31 +126,37 @@ def test_oracle_reproduces_recorded_omp3_runs(pins, make_problem, cs, i):
     assert run.tally_sum() == pytest.approx(r["tally"], rel=1e-13)
 
 
-def _known_answer(make_problem, cs, name, pins=None):
-    d = decks.STANDARD_DECKS[name]
-    run, facets, collisions, _ = _run_oracle(make_problem, cs, name, d["nx"], d["nparticles"],
-                                             d["iterations"])
+_default_deck_runs = {}
+
+
+def _default_deck_run(make_problem, cs, name):
+    """The oracle on a deck as shipped (4000^2 cells); run once per session."""
+    if name not in _default_deck_runs:
+        d = decks.STANDARD_DECKS[name]
+        run, facets, collisions, _ = _run_oracle(make_problem, cs, name, d["nx"], d["nparticles"],
+                                                 d["iterations"])
+        _default_deck_runs[name] = (run.tally_sum(), facets, collisions)
+    return _default_deck_runs[name]
+
+
+@pytest.mark.parametrize("name", ["stream", "csp", "scatter"])
+def test_reference_held__known_answers_default_decks(make_problem, cs, name):
+    """problems/neutral.tests:1-3 at the decks' default sizes (4000^2 cells; 1e6, 1e6,
+    1e7 particles; 1, 10, 2 iterations), the reference's own tolerance.  scatter is
+    the long one: 7e9 collisions, about two minutes on eight cores."""
+    tally, _, _ = _default_deck_run(make_problem, cs, name)
     expected = decks.KNOWN_ANSWERS[name]
-    assert abs(run.tally_sum() - expected) / expected < decks.VALIDATE_TOLERANCE
-    if pins is not None:
-        # the omp3 backend's own output at this size, recorded by the survey
-        rec = next(r for r in pins["omp3_default_runs"] if r["deck"] == name)
-        if rec["facets"] is not None:
-            assert facets == rec["facets"]
-        if rec["collisions"] is not None:
-            assert collisions == rec["collisions"]
-        assert run.tally_sum() == pytest.approx(rec["tally"], rel=1e-13)
+    assert abs(tally - expected) / expected < decks.VALIDATE_TOLERANCE
 
 
-def test_known_answer_stream_default_deck(make_problem, cs, pins):
-    """problems/neutral.tests:2 at the deck's default size (4000^2, 1e6 particles)."""
-    _known_answer(make_problem, cs, "stream", pins)
-
-
-@pytest.mark.fullkat
-@pytest.mark.skipif(os.environ.get("NEUTRAL_FULL_KATS") != "1",
-                    reason="minutes of CPU; set NEUTRAL_FULL_KATS=1 (log: oracle/pins/)")
-@pytest.mark.parametrize("name", ["csp", "scatter"])
-def test_known_answer_default_decks(make_problem, cs, name, pins):
-    """problems/neutral.tests:1,3 at the decks' default sizes."""
-    _known_answer(make_problem, cs, name, pins)
+@pytest.mark.parametrize("name", ["stream", "csp", "scatter"])
+def test_recorded_not_reproducible_here__omp3_default_decks(make_problem, cs, pins, name):
+    """The omp3 backend's own output at the default sizes as the survey recorded it:
+    exact event counts, tally to 1e-13."""
+    tally, facets, collisions = _default_deck_run(make_problem, cs, name)
+    rec = next(r for r in pins["omp3_default_runs"] if r["deck"] == name)
+    if rec["facets"] is not None:
+        assert facets == rec["facets"]
+    if rec["collisions"] is not None:
+        assert collisions == rec["collisions"]
+    assert tally == pytest.approx(rec["tally"], rel=1e-13)

@@ -105,7 +105,7 @@ def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, 
     _same(want, got)
     stats = got[3]
     assert stats[0].stream_passes > 2, "the case no longer migrates"
-    assert stats[0].host_syncs > 1          # first step: one look per pass
+    assert stats[0].host_syncs > 1          # first step: batches of 2, 2, 4, 8 ... passes
     for s in stats[1:]:
         assert s.host_syncs == 1, (s.host_syncs, s.stream_passes, s.stream_passes_enqueued)
         assert s.stream_passes <= s.stream_passes_enqueued
@@ -131,8 +131,9 @@ def test_a_step_that_outruns_the_plan_is_finished(iface, make_problem, cs, monke
     _same(want, got)
     s1, s2 = got[3]
     assert s1.stream_passes == 1
-    assert s2.stream_passes > s2.stream_passes_enqueued - 1 and s2.stream_passes > 2
-    assert s2.host_syncs > 1
+    # two passes were enqueued on the strength of step 1; the rest came in batches
+    assert s2.stream_passes > 2 and s2.host_syncs > 1
+    assert s2.stream_passes <= s2.stream_passes_enqueued
 
 
 def test_the_soa_arrays_are_current_after_every_step(iface, make_problem, cs):
