@@ -238,6 +238,24 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
 void neutral_hip_set_lazy_export(int lazy);
 void neutral_hip_sync_particles(NeutralHipParticle* particles);
 void neutral_hip_invalidate_particles(NeutralHipParticle* particles);
+/* ---- scalar-flux tally -------------------------------------------------------------
+ * The reference declares `double* scalar_flux_tally` in NeutralData (neutral_data.h:95)
+ * and never allocates or writes it, in any backend; the interface has no argument
+ * for it.  This library keeps it when asked: the path-length estimator
+ *     flux[cell] += (1 / ntotal_particles) * sum of weight * segment length
+ * over the track segments a particle lays down in the cell (what collision, facet
+ * and census events move it by; `weight` the weight it travels with), flushed to the
+ * mesh exactly where the energy deposition is (facet, census, death).  Same layout
+ * and normalisation as energy_deposition_tally: ny*nx doubles, accumulated, never
+ * zeroed here, [device] coarse-grained memory.  NULL (default) turns it off, and
+ * the kernels that run then are the ones without any flux code.  With it, the
+ * tiled variant keeps two 88 x 88-cell windows in LDS instead of one of 128 x 128.
+ * With several ranks it is all-reduced per step like the energy tally.
+ * Checked against the CPU oracle's restatement of this definition and by what the
+ * definition implies (tests/test_scalar_flux.py): in a collision-free deck
+ * energy tally / flux is one constant, and the flux sums to speed * dt. */
+void neutral_hip_set_scalar_flux_tally(double* device_tally);
+
 /* ---- ranks: one process per GPU on one node ------------------------------------
  * The reference leaves rank and rank count to the parent project's initialise_mpi
  * (main.c:62) and calls barrier() (main.c:75,112) and reduce_all_sum

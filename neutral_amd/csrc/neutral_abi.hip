@@ -114,6 +114,9 @@ struct State {
   int host_syncs = 0;              /* waits for the device inside the current call */
   /* ranks: particle stores made by inject_particles (this rank's shards) and the
    * per-step tally that is all-reduced before it joins the caller's mesh */
+  double* flux_tally = nullptr; /* scalar-flux tally of the caller (null: not kept) */
+  double* d_step_flux = nullptr; /* several ranks: this step's contributions to it */
+  size_t step_flux_cells = 0;
   int auto_shard = 1;
   struct Store {
     const void* key; /* particles->x */
@@ -252,7 +255,7 @@ void drop_records() {
 /* (Re)allocates the tiled variant's workspace for this problem size. */
 void ensure_tiled_workspace(int nx, int ny, int nparticles) {
   int tx, ty, max_chunks;
-  const int shift = neutral::tiled_tile_shift(nx, ny, nparticles);
+  const int shift = neutral::tiled_tile_shift(nx, ny, nparticles, g.flux_tally != nullptr);
   neutral::tiled_geometry(nx, ny, nparticles, shift, &tx, &ty, &max_chunks);
   neutral::TiledArgs& t = g.tiled;
   const bool grow = nparticles > g.tiled_particles || tx * ty > g.tiled_tiles;
@@ -261,6 +264,12 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
      * may be about to go: a pending write-back of their owner comes first */
     sync_soa();
     drop_records();
+  }
+  if (g.flux_tally && (grow || !t.susp_track)) {
+    /* pending weight * path length of time-sliced histories (scalar flux only) */
+    if (t.susp_track) HIP_CHECK(hipFree(t.susp_track));
+    const size_t cap = (size_t)(grow ? nparticles : g.tiled_particles);
+    HIP_CHECK(hipMalloc((void**)&t.susp_track, sizeof(double) * (cap ? cap : 1)));
   }
   if (grow) {
     void* old[] = {t.order,   t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor,
@@ -444,6 +453,13 @@ void exchange_step(const neutral::SolveArgs& a, double* tally) {
                      g.stream, tally, (const double*)a.tally, ncells);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemsetAsync(a.tally, 0, sizeof(double) * ncells, g.stream));
+  if (g.flux_tally) { /* the scalar-flux mesh travels the same way */
+    neutral::comm_allreduce_sum(a.flux_tally, ncells, true, g.stream);
+    hipLaunchKernelGGL(add_step_tally_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
+                       g.stream, g.flux_tally, (const double*)a.flux_tally, ncells);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemsetAsync(a.flux_tally, 0, sizeof(double) * ncells, g.stream));
+  }
 }
 
 const State::Store* find_store(const NeutralHipParticle* p) {
@@ -467,6 +483,16 @@ void forget_store(const NeutralHipParticle* p) {
       return;
     }
   }
+}
+
+double* step_flux(size_t ncells) {
+  if (ncells > g.step_flux_cells) {
+    if (g.d_step_flux) HIP_CHECK(hipFree(g.d_step_flux));
+    HIP_CHECK(hipMalloc((void**)&g.d_step_flux, sizeof(double) * ncells));
+    g.step_flux_cells = ncells;
+  }
+  HIP_CHECK(hipMemsetAsync(g.d_step_flux, 0, sizeof(double) * ncells, g.stream));
+  return g.d_step_flux;
 }
 
 /* this step's tally contributions when several ranks share the problem */
@@ -578,6 +604,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.edgex = edgex;
   a.edgey = edgey;
   a.tally = energy_deposition_tally;
+  a.flux_tally = g.flux_tally;
+  a.susp_track = nullptr;
   a.counters = g.d_counters;
   a.queue = nullptr;
   a.queue_len = nullptr;
@@ -696,6 +724,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     const bool exchange = neutral::comm_nranks() > 1;
     if (exchange) {
       a.tally = step_tally((size_t)nx * (size_t)ny);
+      if (g.flux_tally) {
+        a.flux_tally = step_flux((size_t)nx * (size_t)ny);
+      }
     }
     HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
     if (tiled) {
@@ -1080,6 +1111,8 @@ void neutral_hip_invalidate_particles(NeutralHipParticle* particles) {
     drop_records();
   }
 }
+
+void neutral_hip_set_scalar_flux_tally(double* device_tally) { g.flux_tally = device_tally; }
 
 void neutral_hip_set_auto_shard(int on) { g.auto_shard = on ? 1 : 0; }
 

@@ -42,6 +42,7 @@ struct History {
   /* locals of handle_particles that live across events */
   double local_density, micro_s, micro_a, number_density, macro_s, macro_a, speed;
   double energy_deposition;
+  double track_length; /* weight * path length not yet tallied: scalar-flux tally only */
   /* Values the reference recomputes at every event although their inputs only
    * change at a collision, a reflection or a density change; they are
    * recomputed here exactly when an input changes (same operations on the same
@@ -65,8 +66,16 @@ struct History {
 
 /* ---- tally policies: WHERE update_tallies (omp3/neutral.c:408-420) adds -------- */
 
+/* Every policy also says whether the scalar-flux tally (neutral_data.h:95; the
+ * path-length estimator sum(weight * segment length) / N per cell, flushed where
+ * the energy deposition is -- defined in oracle/neutral_oracle.c, the reference only
+ * declares the array) is kept: kFlux is a compile-time property, so the event bodies
+ * of the default build carry no trace of it. */
+
 /* straight to the mesh in HBM: one global_atomic_add_f64 per tally */
-struct GlobalTally {
+template <bool kWithFlux>
+struct GlobalTallyT {
+  static constexpr bool kFlux = kWithFlux;
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
     const int cellx = pcellx - a.x_off;
@@ -78,62 +87,88 @@ struct GlobalTally {
     unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), energy_deposition * a.inv_ntotal_particles);
 #endif
   }
+  __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
+                                       double track_length) const {
+    unsafeAtomicAdd(mesh_element(a.flux_tally, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)),
+                    track_length * a.inv_ntotal_particles);
+  }
 };
+typedef GlobalTallyT<false> GlobalTally;
 
 /* into a W x W window of the mesh held in LDS (ds_add_f64) when the cell lies
- * inside it, to HBM otherwise; the owner flushes the window to the mesh */
+ * inside it, to HBM otherwise; the owner flushes the window to the mesh.  With the
+ * scalar-flux tally a second window of the same geometry follows the first. */
 typedef __attribute__((address_space(3))) double lds_double;
 
-template <int W>
-struct WindowTally {
-  lds_double* window; /* LDS, W*W, row-major */
+/* window edge in cells: one 128 x 128 window (128 KB) fills the LDS next to the cs
+ * index; two windows of 88 x 88 (121 KB) take its place when the flux is kept */
+constexpr int kWindowCells = 128;
+constexpr int kWindowCellsWithFlux = 88;
+
+template <bool kWithFlux>
+struct WindowTallyT {
+  static constexpr bool kFlux = kWithFlux;
+  static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
+  lds_double* window; /* LDS, W*W, row-major (flux: the next W*W) */
   int ox;         /* local cell coordinates of window element (0,0) */
   int oy;
-  __device__ __forceinline__ bool inside(const SolveArgs& a, int pcellx, int pcelly) const {
-    return (unsigned)(pcellx - a.x_off - ox) < (unsigned)W &&
-           (unsigned)(pcelly - a.y_off - oy) < (unsigned)W;
-  }
-  __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
-                                             double energy_deposition) const {
+  __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
+                                      unsigned which, double* mesh) const {
     const int cellx = pcellx - a.x_off;
     const int celly = pcelly - a.y_off;
     const unsigned lx = (unsigned)(cellx - ox);
     const unsigned ly = (unsigned)(celly - oy);
-    const double v = energy_deposition * a.inv_ntotal_particles;
-#if defined(NEUTRAL_EXP_NO_TALLY)
-    if (v == 1.2345e300) window[0] = v; /* timing experiment only */
-    return;
-#endif
     if (lx < (unsigned)W && ly < (unsigned)W) {
       /* ds_add_f64, no return value */
-      (void)__hip_atomic_fetch_add(&window[ly * W + lx], v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + ly * (unsigned)W + lx], v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), v);
+      unsafeAtomicAdd(mesh_element(mesh, celly * a.nx + cellx), v);
     }
+  }
+  __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
+                                             double energy_deposition) const {
+#if defined(NEUTRAL_EXP_NO_TALLY)
+    if (energy_deposition == 1.2345e300) window[0] = energy_deposition; /* timing experiment only */
+    return;
+#endif
+    add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
+  }
+  __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
+                                       double track_length) const {
+    add(a, pcellx, pcelly, track_length * a.inv_ntotal_particles, 1u, a.flux_tally);
   }
 };
 
 /* The same destination for a cell whose window coordinates the caller has already
  * worked out (the stream kernel needs them anyway, to decide whether a particle
  * that left the window should wait for the next pass). */
-struct WindowCellTally {
+template <bool kWithFlux>
+struct WindowCellTallyT {
+  static constexpr bool kFlux = kWithFlux;
+  static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */
-  int W;
+  __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
+                                      unsigned which, double* mesh) const {
+    if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
+      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + ly * (unsigned)W + lx], v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      unsafeAtomicAdd(mesh_element(mesh, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
+    }
+  }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
-    const double v = energy_deposition * a.inv_ntotal_particles;
 #if defined(NEUTRAL_EXP_NO_TALLY)
-    if (v == 1.2345e300) window[0] = v; /* timing experiment only */
+    if (energy_deposition == 1.2345e300) window[0] = energy_deposition; /* timing experiment only */
     return;
 #endif
-    if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
-      (void)__hip_atomic_fetch_add(&window[ly * (unsigned)W + lx], v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-      unsafeAtomicAdd(mesh_element(a.tally, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
-    }
+    add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
+  }
+  __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
+                                       double track_length) const {
+    add(a, pcellx, pcelly, track_length * a.inv_ntotal_particles, 1u, a.flux_tally);
   }
 };
 
@@ -422,6 +457,7 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   macroscopic_from_density(h);
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
+  h.track_length = 0.0;
   h.counter = 0;
   h.nevents = 0;
   h.dt_to_census = a.dt;
@@ -448,6 +484,7 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   macroscopic_from_density(h);
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
+  h.track_length = 0.0;
   h.counter = 1;
   h.nevents = 0;
   refresh_direction(h);
@@ -526,6 +563,9 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
                                         const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
   h.energy_deposition += deposit(h, distance_to_collision);
+  if (Tally::kFlux) {
+    h.track_length += h.weight * distance_to_collision; /* (the weight it travelled with) */
+  }
   h.x += distance_to_collision * h.omega_x;
   h.y += distance_to_collision * h.omega_y;
 
@@ -543,6 +583,10 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
       h.dead = 1;
       tally(a, h.cellx, h.celly, h.energy_deposition);
       h.energy_deposition = 0.0;
+      if (Tally::kFlux) {
+        tally.flux(a, h.cellx, h.celly, h.track_length);
+        h.track_length = 0.0;
+      }
       return true;
     }
   }
@@ -636,6 +680,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   h.energy_deposition += deposit(h, distance_to_facet);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   h.energy_deposition = 0.0;
+  if (Tally::kFlux) {
+    tally.flux(a, h.cellx, h.celly, h.track_length + h.weight * distance_to_facet);
+    h.track_length = 0.0;
+  }
 
   h.x += distance_to_facet * h.omega_x;
   h.y += distance_to_facet * h.omega_y;
@@ -673,6 +721,10 @@ __device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tal
   h.mfp_to_collision -= (distance_to_census / h.cell_mfp);
   h.energy_deposition += deposit(h, distance_to_census);
   tally(a, h.cellx, h.celly, h.energy_deposition);
+  if (Tally::kFlux) {
+    tally.flux(a, h.cellx, h.celly, h.track_length + h.weight * distance_to_census);
+    h.track_length = 0.0;
+  }
   h.dt_to_census = 0.0;
 }
 

@@ -49,6 +49,8 @@ struct alignas(16) SuspendExtra {
   unsigned counter;
   unsigned nevents;
 };
+/* (with the scalar-flux tally the pending weight * path length of such a history
+ * lives in a parallel array of doubles: TiledArgs::susp_track) */
 
 struct InjectArgs {
   int nparticles;
@@ -114,6 +116,7 @@ struct SolveArgs {
   long long absorb_index_base;
   int index_shift;
   double* tally;
+  double* flux_tally; /* scalar-flux tally (null: not kept; see neutral_hip.h) */
   StepCounters* counters;
   /* optional work list for the regroup kernel: ids of particles another kernel
    * suspended at their first collision (null: all particles 0..nparticles-1) */
@@ -126,6 +129,7 @@ struct SolveArgs {
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
   int tile_shift;            /* log2 of the tile edge in cells (4..7) */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
+  double* susp_track;        /* ... their pending weight * path length (scalar flux only) */
   /* tiled variant: a history that ends also writes its final state to the SoA store
    * `p` at its id, so the interface's arrays are current when solve_transport_2d
    * returns (0: lazy export, the records are written back on demand) */
@@ -156,6 +160,7 @@ struct TiledArgs {
   uint4* chunks;           /* max_chunks: {begin, end, tile, windowed} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
+  double* susp_track;      /* nparticles, only with the scalar-flux tally (else null) */
   /* finer bucketed index for the collision stage (identical tables only; null: none) */
   const unsigned short* fine_index;
   int fine_index_n;
@@ -214,7 +219,7 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
 hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream);
 /* tile edge (log2 cells) and window threshold for a problem; tiles and chunk capacity */
-int tiled_tile_shift(int nx, int ny, int nparticles);
+int tiled_tile_shift(int nx, int ny, int nparticles, bool with_flux);
 int tiled_window_min_particles(int tile_shift);
 void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
                     int* max_chunks);

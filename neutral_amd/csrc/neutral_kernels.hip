@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void inject_kernel(InjectArgs a) {
 
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
-template <bool kSameTables>
+template <bool kSameTables, bool kFlux>
 __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(SolveArgs a) {
   const int pid = blockIdx.x * kBlock + threadIdx.x;
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
   if (pid < a.nparticles && !a.p.dead[pid]) { /* omp3/neutral.c:91-93 */
     nprocessed = 1;
     const CsLookup<const unsigned short*> ix{a.scatter_index, a.absorb_index};
-    const GlobalTally tally;
+    const GlobalTallyT<kFlux> tally;
     History h;
     load_particle(h, a, pid);
     prologue<kSameTables>(h, a, ix);
@@ -265,7 +265,7 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * colliders mixed (parked lanes make occupancy matter: 4 waves/SIMD, small
  * spill); kQueue = true: the collision stage of the tiled pipeline, histories
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
-template <bool kSameTables, bool kQueue>
+template <bool kSameTables, bool kQueue, bool kFlux>
 __global__ __launch_bounds__(kBlock, kQueue ? NEUTRAL_K2_QUEUE_WAVES : NEUTRAL_K2_WAVES)
 void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
@@ -297,7 +297,7 @@ void history_regroup_kernel(SolveArgs a) {
     __syncthreads();
   }
 
-  const GlobalTally tally;
+  const GlobalTallyT<kFlux> tally;
   /* work list: particle ids 0..nparticles-1, or the ids another kernel queued */
   const int nwork = kQueue ? (int)*a.queue_len : a.nparticles;
   /* A history is a serial chain (931 collisions of ~7 us for a csp collider), so
@@ -419,6 +419,9 @@ void history_regroup_kernel(SolveArgs a) {
           h.energy_deposition = x.energy_deposition;
           h.counter = x.counter;
           h.nevents = x.nevents;
+          if (kFlux) {
+            h.track_length = a.susp_track[pid];
+          }
         }
         next_event(true);
         want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
@@ -522,6 +525,9 @@ void history_regroup_kernel(SolveArgs a) {
           x.counter = h.counter;
           x.nevents = h.nevents;
           a.susp[pid] = x;
+          if (kFlux) {
+            a.susp_track[pid] = h.track_length;
+          }
           /* outstanding histories never exceed the share: the slot is free */
           int back = ring_head + ring_count;
           back = (back >= share) ? back - share : back;
@@ -885,24 +891,30 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       }
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
     };
-    if (a.queue) {
-      if (a.same_tables) {
-        launch(history_regroup_kernel<true, true>);
-      } else {
-        launch(history_regroup_kernel<false, true>);
-      }
-    } else if (a.same_tables) {
-      launch(history_regroup_kernel<true, false>);
-    } else {
-      launch(history_regroup_kernel<false, false>);
+    /* (the scalar-flux tally is a compile-time property of a kernel: the default
+     * instantiations carry no trace of it) */
+    const int pick = (a.queue ? 4 : 0) | (a.same_tables ? 2 : 0) | (a.flux_tally ? 1 : 0);
+    switch (pick) {
+      case 7: launch(history_regroup_kernel<true, true, true>); break;
+      case 6: launch(history_regroup_kernel<true, true, false>); break;
+      case 5: launch(history_regroup_kernel<false, true, true>); break;
+      case 4: launch(history_regroup_kernel<false, true, false>); break;
+      case 3: launch(history_regroup_kernel<true, false, true>); break;
+      case 2: launch(history_regroup_kernel<true, false, false>); break;
+      case 1: launch(history_regroup_kernel<false, false, true>); break;
+      default: launch(history_regroup_kernel<false, false, false>); break;
     }
     return hipGetLastError();
   }
   const int grid = (a.nparticles + kBlock - 1) / kBlock;
-  if (a.same_tables) {
-    hipLaunchKernelGGL(history_kernel<true>, dim3(grid), dim3(kBlock), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL(history_kernel<false>, dim3(grid), dim3(kBlock), 0, stream, a);
+  auto launch1 = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+  };
+  switch ((a.same_tables ? 2 : 0) | (a.flux_tally ? 1 : 0)) {
+    case 3: launch1(history_kernel<true, true>); break;
+    case 2: launch1(history_kernel<true, false>); break;
+    case 1: launch1(history_kernel<false, true>); break;
+    default: launch1(history_kernel<false, false>); break;
   }
   return hipGetLastError();
 }

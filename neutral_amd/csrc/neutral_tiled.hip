@@ -56,7 +56,8 @@
 
 namespace neutral {
 
-constexpr int kWindow = 128;                       /* cells per LDS window edge */
+constexpr int kWindow = kWindowCells; /* cells per LDS window edge (neutral_history.h; 88 and
+                                         two windows when the scalar flux is kept) */
 #ifndef NEUTRAL_STREAM_BLOCK
 #define NEUTRAL_STREAM_BLOCK 1024
 #endif
@@ -484,26 +485,30 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
 
 /* ---- 2. streaming kernel with the LDS tally window ------------------------------ */
 
-__device__ __forceinline__ void flush_window(const SolveArgs& a, double* window, int ox, int oy) {
+template <int kW>
+__device__ __forceinline__ void flush_window(const SolveArgs& a, double* window, double* mesh,
+                                             int ox, int oy) {
   /* row-contiguous: one wave instruction adds 64 consecutive cells (512 B) */
-  for (int i = threadIdx.x; i < kWindow * kWindow; i += kStreamBlock) {
+  for (int i = threadIdx.x; i < kW * kW; i += kStreamBlock) {
     const double v = window[i];
     window[i] = 0.0;
     if (v != 0.0) {
-      const int gx = ox + (i % kWindow);
-      const int gy = oy + (i / kWindow);
+      const int gx = ox + (i % kW);
+      const int gy = oy + (i / kW);
       if (gx >= 0 && gx < a.nx && gy >= 0 && gy < a.ny) {
-        unsafeAtomicAdd(&a.tally[gy * a.nx + gx], v);
+        unsafeAtomicAdd(&mesh[gy * a.nx + gx], v);
       }
     }
   }
 }
 
-template <bool kSameTables>
+template <bool kSameTables, bool kFlux>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
+  constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
+  constexpr int kWindows = kFlux ? 2 : 1;
   extern __shared__ double lds_raw[];
-  double* window = lds_raw;                                             /* kWindow^2 f64 */
-  unsigned short* lds_index = (unsigned short*)(lds_raw + kWindow * kWindow);
+  double* window = lds_raw;                                             /* kWindows * kW^2 f64 */
+  unsigned short* lds_index = (unsigned short*)(lds_raw + kWindows * kW * kW);
   __shared__ int s_chunk;
   __shared__ int s_end;
   __shared__ int s_tile;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       ix.absorb_index = lds_index + used;
     }
-    for (int i = threadIdx.x; i < kWindow * kWindow; i += kStreamBlock) {
+    for (int i = threadIdx.x; i < kWindows * kW * kW; i += kStreamBlock) {
       window[i] = 0.0;
     }
   }
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
   int win_ox = 0;
   int win_oy = 0;
-  WindowTally<kWindow> tally{(lds_double*)window, 0, 0};
+  WindowTallyT<kFlux> tally{(lds_double*)window, 0, 0};
 
   unsigned nfacets = 0;     /* per lane */
   unsigned w_processed = 0; /* per wave (uniform) */
@@ -580,11 +585,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
     if (windowed && chunk_tile != cur_tile) {
       /* move the window: flush what the previous tile accumulated */
       if (cur_tile >= 0) {
-        flush_window(a, window, win_ox, win_oy);
+        flush_window<kW>(a, window, a.tally, win_ox, win_oy);
+        if (kFlux) {
+          flush_window<kW>(a, window + kW * kW, a.flux_tally, win_ox, win_oy);
+        }
       }
       cur_tile = chunk_tile;
-      /* the window reaches (128 - T) / 2 cells beyond the T x T tile on every side */
-      const int margin = (kWindow - (1 << t.tile_shift)) >> 1;
+      /* the window reaches (W - T) / 2 cells beyond the T x T tile on every side */
+      const int margin = (kW - (1 << t.tile_shift)) >> 1;
       win_ox = ((cur_tile % t.tiles_x) << t.tile_shift) - margin;
       win_oy = ((cur_tile / t.tiles_x) << t.tile_shift) - margin;
       __syncthreads();
@@ -653,11 +661,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             /* outside the window with a long way to go: continue in the pass that
              * centres a window on wherever the particle is by then */
             bool leave = false;
-            const WindowCellTally cell_tally{tally.window,
-                                             (unsigned)(h.cellx - a.x_off - tally.ox),
-                                             (unsigned)(h.celly - a.y_off - tally.oy), kWindow};
-            const bool in_window = (cell_tally.lx < (unsigned)kWindow) &
-                                   (cell_tally.ly < (unsigned)kWindow);
+            const WindowCellTallyT<kFlux> cell_tally{tally.window,
+                                                     (unsigned)(h.cellx - a.x_off - tally.ox),
+                                                     (unsigned)(h.celly - a.y_off - tally.oy)};
+            const bool in_window = (cell_tally.lx < (unsigned)kW) & (cell_tally.ly < (unsigned)kW);
             if (windowed && t.allow_migrate && !in_window) {
               const double ahead = h.speed * h.dt_to_census;
               const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
@@ -733,7 +740,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
     atomicAdd(&t.ctrl[kCtrlMigrants], w_migrants);
   }
   if (cur_tile >= 0) {
-    flush_window(a, window, win_ox, win_oy);
+    flush_window<kW>(a, window, a.tally, win_ox, win_oy);
+    if (kFlux) {
+      flush_window<kW>(a, window + kW * kW, a.flux_tally, win_ox, win_oy);
+    }
   }
   {
     const unsigned wf = wave_sum_u32(nfacets);
@@ -748,7 +758,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
 /* ---- launcher ---------------------------------------------------------------------- */
 
 size_t tiled_lds_bytes(const SolveArgs& a) {
-  size_t lds = sizeof(double) * kWindow * kWindow;
+  size_t lds = a.flux_tally ? sizeof(double) * 2 * kWindowCellsWithFlux * kWindowCellsWithFlux
+                            : sizeof(double) * kWindow * kWindow;
   if (a.scatter_index) {
     lds += sizeof(unsigned short) * (a.scatter_index_n + 1);
   }
@@ -769,7 +780,7 @@ int tiled_chunk_particles(int nparticles, int compute_units) {
   return (int)c;
 }
 
-int tiled_tile_shift(int nx, int ny, int nparticles) {
+int tiled_tile_shift(int nx, int ny, int nparticles, bool with_flux) {
   /* Tile edge T = 16 << k cells under the fixed 128-cell window.  A tile is worth a
    * window when enough particles stream through it to pay for the window's flush; the
    * estimate is the mean particle density (particles per cell): 16-cell tiles from 8
@@ -777,17 +788,20 @@ int tiled_tile_shift(int nx, int ny, int nparticles) {
    * window itself, no margin -- below 0.5 (the reference's decks as shipped: 4000^2
    * cells, 1e6 particles, 0.06 per cell; their particles cross thousands of cells per
    * step and enter every window at an edge anyway).  NEUTRAL_TILE_CELLS overrides. */
+  /* (with the scalar flux two 88-cell windows share the LDS: tiles of at most 64) */
+  const int largest = with_flux ? 6 : 7;
   const char* force = getenv("NEUTRAL_TILE_CELLS");
   if (force) {
     const int cells = atoi(force);
-    for (int shift = 4; shift <= 7; ++shift) {
+    for (int shift = 4; shift <= largest; ++shift) {
       if (cells == (1 << shift)) {
         return shift;
       }
     }
   }
   const double density = (double)nparticles / ((double)nx * (double)ny);
-  return (density >= 8.0) ? 4 : (density >= 2.0) ? 5 : (density >= 0.5) ? 6 : 7;
+  const int shift = (density >= 8.0) ? 4 : (density >= 2.0) ? 5 : (density >= 0.5) ? 6 : 7;
+  return shift < largest ? shift : largest;
 }
 
 int tiled_window_min_particles(int tile_shift) {
@@ -856,10 +870,21 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
     }
   }
   /* one 1024-thread workgroup per CU (the window takes most of the LDS) */
-  if (a.same_tables) {
-    hipLaunchKernelGGL(stream_kernel<true>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+  auto launch = [&](auto kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+  };
+  if (a.flux_tally) {
+    if (a.same_tables) {
+      launch(stream_kernel<true, true>);
+    } else {
+      launch(stream_kernel<false, true>);
+    }
+  } else if (a.same_tables) {
+    launch(stream_kernel<true, false>);
   } else {
-    hipLaunchKernelGGL(stream_kernel<false>, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
+    launch(stream_kernel<false, false>);
   }
   return hipGetLastError();
 }
@@ -882,10 +907,6 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
   const size_t lds = tiled_lds_bytes(a);
-  (void)hipFuncSetAttribute((const void*)stream_kernel<true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipFuncSetAttribute((const void*)stream_kernel<false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
@@ -934,6 +955,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.tiles_x = t.tiles_x;
   c.tile_shift = t.tile_shift;
   c.susp = t.susp;
+  c.susp_track = t.susp_track;
   if (t.fine_index && c.same_tables) {
     c.scatter_index = t.fine_index;
     c.scatter_index_n = t.fine_index_n;

@@ -81,7 +81,7 @@ ABI_SYMBOLS = (
     "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
     "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
-    "neutral_hip_invalidate_particles",
+    "neutral_hip_invalidate_particles", "neutral_hip_set_scalar_flux_tally",
     "neutral_hip_comm_start", "neutral_hip_comm_stop", "neutral_hip_comm_rank",
     "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_set_auto_shard",
     "neutral_hip_store_count", "neutral_hip_comm_allreduce_f64", "neutral_hip_comm_max",
@@ -129,6 +129,7 @@ _lib.neutral_hip_free_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_set_lazy_export.argtypes = [C.c_int]
 _lib.neutral_hip_sync_particles.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_invalidate_particles.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_set_scalar_flux_tally.argtypes = [C.c_void_p]
 _lib.neutral_hip_comm_start.restype = C.c_int
 _lib.neutral_hip_comm_rank.restype = C.c_int
 _lib.neutral_hip_comm_nranks.restype = C.c_int
@@ -341,7 +342,7 @@ class Simulation:
     """
 
     def __init__(self, problem, cs_keys, cs_values, device: int = 0, shard=None,
-                 cs_absorb=None, variant: Optional[int] = None):
+                 cs_absorb=None, variant: Optional[int] = None, scalar_flux: bool = False):
         import torch
 
         if not torch.cuda.is_available():
@@ -370,6 +371,9 @@ class Simulation:
         self.density = dev(problem.density)
         self.tally = torch.zeros(problem.nx * problem.ny, dtype=torch.float64,
                                  device=self.device)
+        # scalar-flux tally (include/neutral_hip.h): optional second mesh
+        self.flux = torch.zeros(problem.nx * problem.ny, dtype=torch.float64,
+                                device=self.device) if scalar_flux else None
         self._sk, self._sv = dev(cs_keys), dev(cs_values)
         if cs_absorb is None:
             # two separate device copies, as neutral_data.c:176-177 reads both files
@@ -413,6 +417,8 @@ class Simulation:
         if self.variant is not None:
             set_variant(self.variant)
         facets, collisions = C.c_uint64(0), C.c_uint64(0)
+        _lib.neutral_hip_set_scalar_flux_tally(
+            C.c_void_p(self.flux.data_ptr()) if self.flux is not None else None)
         solve_transport_2d(
             p.nx - 2 * p.pad, p.ny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, p.x_off,
             p.y_off, p.dt, p.nparticles, self.nlocal, None, self.particles,

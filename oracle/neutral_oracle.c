@@ -205,6 +205,21 @@ static inline void tally_add(double* tally, int nx, int x_off, int y_off,
   tally[celly * nx + cellx] += energy_deposition * inv_ntotal_particles;
 }
 
+/* ---- scalar-flux tally (neutral_data.h:95) ------------------------------------
+ * The reference DECLARES `double* scalar_flux_tally` and never allocates or writes
+ * it in any backend, so there is no reference behaviour to restate.  This is the
+ * definition the HIP path implements and is checked against here: the path-length
+ * estimator of the scalar flux with the energy tally's own normalisation and flush
+ * points --
+ *     flux[cell] += (1/N) * sum over the track segments in the cell of weight * length
+ * a segment being what collision_event / facet_event / census_event move the
+ * particle by (omp3/neutral.c:227-228, 329-330, 391-392), `weight` the weight it
+ * is moved with (before an absorption at the segment's end reduces it, :241), and
+ * the sum flushed to the mesh where the energy deposition is (:249, :325, :397).
+ * Off unless a mesh is set. */
+static double* g_scalar_flux_tally = NULL;
+void orc_set_scalar_flux_tally(double* tally) { g_scalar_flux_tally = tally; }
+
 /* census events of the most recent orc_solve_transport_2d call (bookkeeping for
  * the particle-steps metric; the reference does not count them) */
 static uint64_t g_last_census = 0;
@@ -279,6 +294,8 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
         number_density * microscopic_cs_absorb * ORC_BARNS;
     double speed = sqrt((2.0 * energy * ORC_eV_TO_J) / ORC_PARTICLE_MASS);
     double energy_deposition = 0.0;
+    double track_length = 0.0; /* weight * path length not yet tallied (scalar flux) */
+    double* const flux_tally = g_scalar_flux_tally;
 
     const double inv_ntotal_particles = 1.0 / (double)ntotal_particles;
 
@@ -311,6 +328,7 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
             energy, weight, distance_to_collision, number_density,
             microscopic_cs_absorb,
             microscopic_cs_scatter + microscopic_cs_absorb);
+        track_length += weight * distance_to_collision;
 
         px += distance_to_collision * omega_x;
         py += distance_to_collision * omega_y;
@@ -330,6 +348,11 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
             tally_add(energy_deposition_tally, nx, x_off, y_off, pcellx,
                       pcelly, inv_ntotal_particles, energy_deposition);
             energy_deposition = 0.0;
+            if (flux_tally) {
+              tally_add(flux_tally, nx, x_off, y_off, pcellx, pcelly,
+                        inv_ntotal_particles, track_length);
+              track_length = 0.0;
+            }
             break; /* PARTICLE_DEAD, omp3/neutral.c:165-167 */
           }
         } else {
@@ -377,9 +400,16 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
             microscopic_cs_absorb,
             microscopic_cs_scatter + microscopic_cs_absorb);
 
+        track_length += weight * distance_to_facet;
+
         tally_add(energy_deposition_tally, nx, x_off, y_off, pcellx, pcelly,
                   inv_ntotal_particles, energy_deposition);
         energy_deposition = 0.0;
+        if (flux_tally) {
+          tally_add(flux_tally, nx, x_off, y_off, pcellx, pcelly,
+                    inv_ntotal_particles, track_length);
+          track_length = 0.0;
+        }
 
         px += distance_to_facet * omega_x;
         py += distance_to_facet * omega_y;
@@ -432,8 +462,13 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
             energy, weight, distance_to_census, number_density,
             microscopic_cs_absorb,
             microscopic_cs_scatter + microscopic_cs_absorb);
+        track_length += weight * distance_to_census;
         tally_add(energy_deposition_tally, nx, x_off, y_off, pcellx, pcelly,
                   inv_ntotal_particles, energy_deposition);
+        if (flux_tally) {
+          tally_add(flux_tally, nx, x_off, y_off, pcellx, pcelly,
+                    inv_ntotal_particles, track_length);
+        }
         dt_to_census = 0.0;
         ncensus++;
         break;

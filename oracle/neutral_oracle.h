@@ -114,6 +114,12 @@ uint64_t orc_solve_transport_2d(int nx, int ny, int global_nx, int global_ny,
                                 double* energy_deposition_tally,
                                 uint64_t* facets, uint64_t* collisions);
 
+/* Scalar-flux tally (declared, never written, in the reference: neutral_data.h:95):
+ * when set (nx*ny doubles), orc_solve_transport_2d also accumulates the path-length
+ * estimator sum(weight * segment length) / N per cell, flushed where the energy
+ * deposition is.  NULL (default) turns it off.  See neutral_oracle.c. */
+void orc_set_scalar_flux_tally(double* tally);
+
 /* histories of the most recent orc_solve_transport_2d call that ended in a
  * census event (not counted by the reference; needed for particle-steps) */
 uint64_t orc_last_census(void);

@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
             C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
             C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_double,
             C.POINTER(OrcParticles)]
+        L.orc_set_scalar_flux_tally.argtypes = [_dp]
         L.orc_solve_transport_2d.restype = C.c_uint64
         L.orc_solve_transport_2d.argtypes = [
             C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
@@ -156,8 +157,11 @@ class OracleRun:
     [first, first+count): the particle-shard extension.
     """
 
-    def __init__(self, problem, cs_keys, cs_values, shard=None, cs_absorb=None):
+    def __init__(self, problem, cs_keys, cs_values, shard=None, cs_absorb=None,
+                 scalar_flux=False):
         self.p = problem
+        # scalar-flux tally (path-length estimator, oracle/neutral_oracle.c): optional
+        self.flux = np.zeros(problem.nx * problem.ny, dtype=np.float64) if scalar_flux else None
         self.cs_scatter = CsTable(cs_keys, cs_values)
         self.cs_absorb = CsTable(*cs_absorb) if cs_absorb is not None else \
             CsTable(cs_keys, cs_values)
@@ -181,12 +185,14 @@ class OracleRun:
     def step(self, master_key: int) -> StepResult:
         p = self.p
         facets, collisions = C.c_uint64(0), C.c_uint64(0)
+        lib().orc_set_scalar_flux_tally(_ptr(self.flux, _dp) if self.flux is not None else None)
         nproc = lib().orc_solve_transport_2d(
             p.nx - 2 * p.pad, p.ny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, p.x_off,
             p.y_off, p.dt, p.nparticles, self.n, self.pid_base, C.byref(self.particles.c),
             _ptr(self.density, _dp), _ptr(self.edgex, _dp), _ptr(self.edgey, _dp),
             C.byref(self.cs_scatter.c), C.byref(self.cs_absorb.c), _ptr(self.tally, _dp),
             C.byref(facets), C.byref(collisions))
+        lib().orc_set_scalar_flux_tally(None)
         return StepResult(int(nproc), facets.value, collisions.value,
                           int(lib().orc_last_census()))
 
