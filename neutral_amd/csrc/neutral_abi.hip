@@ -110,7 +110,6 @@ struct State {
   /* what the last step of this record store needed: the next step is enqueued on that
    * assumption, without waiting for the device in between (0 / -1: nothing known) */
   int plan_passes = 0;
-  long long plan_queue = -1;
   int host_syncs = 0;              /* waits for the device inside the current call */
   /* ranks: particle stores made by inject_particles (this rank's shards) and the
    * per-step tally that is all-reduced before it joins the caller's mesh */
@@ -249,7 +248,6 @@ void sync_soa() {
 void drop_records() {
   g.rec_valid = false;
   g.plan_passes = 0;
-  g.plan_queue = -1;
 }
 
 /* (Re)allocates the tiled variant's workspace for this problem size. */
@@ -396,15 +394,6 @@ void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCros
   /* every step: the contents against the view (result read with the step's counters) */
   HIP_CHECK(neutral::launch_tables_check(v.keys_s, v.values_s, v.n_s, v.keys_a, v.values_a, v.n_a,
                                          v.hash_s, v.hash_a, v.same, g.d_check, g.stream));
-}
-
-int device_cus() {
-  int dev = 0;
-  int cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
-  return cus;
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -732,14 +721,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     if (tiled) {
       /* Stream passes are enqueued on what the last step needed (plus one, which
        * finds nothing to do when the guess holds) without waiting in between; the
-       * first step of a problem starts with two.  The collision stage's occupancy
-       * follows the last step's queue length. */
+       * first step of a problem starts with two. */
       neutral::TiledPlan plan;
       plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 2;
-      plan.blocks_per_cu =
-          g.plan_queue >= 0
-              ? neutral::tiled_collision_blocks_per_cu((unsigned)g.plan_queue, device_cus())
-              : 0;
+      plan.blocks_per_cu = -1; /* the collision stage sizes itself from its queue */
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, plan, 0, g.ev_sorted,
                                             g.ev_streamed, g.ev_collected, &passes));
     } else {
@@ -784,7 +769,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
      * suspend get a collision stage of their own (the first one's are marked done),
      * and with several ranks their tallies an exchange of their own. */
     while (any_rank(ctrl[4] != 0)) {
-      neutral::TiledPlan more = {passes < 2 ? 2 : passes, 0};
+      neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
                                             g.ev_streamed, g.ev_collected, &passes));
       HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
@@ -810,7 +795,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     t.info_in = t.info_out;
     t.info_out = swap_info;
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
-    g.plan_queue = (long long)queue_total; /* (this rank's own queue) */
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
   }
 

@@ -123,7 +123,8 @@ struct SolveArgs {
   unsigned* queue;           /* (the collision stage re-uses its words as per-wave rings) */
   const unsigned* queue_len; /* [device] number of valid entries */
   ParticleRec* rec;          /* queue entries index this record array (tiled variant) */
-  int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU */
+  int blocks_per_cu;         /* > 0: cap on the regroup kernel's workgroups per CU; -1: the
+                                collision stage picks 1..3 itself from its queue length */
   int max_blocks;            /* > 0: cap on the regroup kernel's grid (test knob) */
   unsigned* slot_info;       /* per-record summary kept next to rec (see TiledArgs) */
   int tiles_x;               /* tiles per mesh row, for the summary's tile field */
@@ -185,7 +186,8 @@ struct TiledArgs {
 struct TiledPlan {
   int stream_passes; /* stream passes to enqueue back to back (steady state: what the
                         last step needed plus one) */
-  int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit) */
+  int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit; -1: chosen by
+                        the kernel from the queue length) */
 };
 
 enum Variant {
@@ -223,7 +225,6 @@ int tiled_tile_shift(int nx, int ny, int nparticles, bool with_flux);
 int tiled_window_min_particles(int tile_shift);
 void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
                     int* max_chunks);
-int tiled_collision_blocks_per_cu(unsigned queued, int cus);
 /* Enqueues plan.stream_passes stream passes starting with pass number first_pass, the
  * collision queue and the collision stage; nothing here waits for the device.
  * a.counters must point at TWO StepCounters records: [0] streaming kernel, [1]

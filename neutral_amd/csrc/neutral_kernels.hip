@@ -276,6 +276,27 @@ void history_regroup_kernel(SolveArgs a) {
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
   }
+  /* Collision stage, launched three workgroups per CU (a.blocks_per_cu == -1): how many
+   * of them work is decided HERE, from the queue length the host has not seen yet.  A
+   * collider is a serial chain of ~10^3 collisions; with few of them the stage lasts
+   * one chain, and a chain runs faster the fewer waves share its SIMD (csp, per chain:
+   * 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two: profiles/r01f), so a
+   * queue that fits one (two) workgroup(s) per CU keeps exactly that many.  Workgroups
+   * b, b + #CUs, b + 2 #CUs share a CU under every dispatch order tried (and nothing
+   * breaks if they do not: this is an occupancy hint), and #CUs = 1 mod 3, so "b mod 3 <
+   * wanted" leaves `wanted` of them on each CU. */
+  int block_index = (int)blockIdx.x;
+  int block_count = (int)gridDim.x;
+  if (kQueue && a.blocks_per_cu == -1) {
+    const unsigned queued = *a.queue_len;
+    const unsigned row_lanes = (gridDim.x / 3u) * (unsigned)kBlock;
+    const int wanted = (queued <= row_lanes) ? 1 : (queued <= 2u * row_lanes) ? 2 : 3;
+    if ((int)(blockIdx.x % 3u) >= wanted) {
+      return;
+    }
+    block_index = (int)(blockIdx.x / 3u) * wanted + (int)(blockIdx.x % 3u);
+    block_count = (int)(gridDim.x / 3u) * wanted;
+  }
   /* stage the bucketed cs index(es) in LDS: nbuckets+1 u16 entries each */
   extern __shared__ unsigned short lds_index[];
   CsLookup<const unsigned short*> ix{nullptr, nullptr};
@@ -305,7 +326,7 @@ void history_regroup_kernel(SolveArgs a) {
    * wave works through.  When there are fewer ids than lanes * 2, claim them in
    * smaller chunks so that every wave gets an equal share instead of a few
    * waves getting two generations each while the other SIMDs idle. */
-  const int nwaves = (int)gridDim.x * (kBlock / 64);
+  const int nwaves = block_count * (kBlock / 64);
   int chunk = (nwork + nwaves - 1) / nwaves;
   chunk = (chunk < NEUTRAL_QUEUE_CHUNK_MIN) ? NEUTRAL_QUEUE_CHUNK_MIN : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
 
@@ -345,7 +366,7 @@ void history_regroup_kernel(SolveArgs a) {
   /* pooled mode (the collision stage): the wave's strided share of the queue is its
    * ring; all wave-uniform */
   const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare);
-  const int gw = (int)blockIdx.x * (kBlock / 64) + (int)(threadIdx.x >> 6);
+  const int gw = block_index * (kBlock / 64) + (int)(threadIdx.x >> 6);
   const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
   int ring_head = 0;      /* ring position of the oldest waiting history, in [0, share) */
   int ring_count = share; /* histories waiting in the ring */
@@ -866,11 +887,26 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     if (lds > (size_t)(160 * 1024 - 64)) {
       return hipErrorInvalidValue; /* the ABI drops an index before this can happen */
     }
+    SolveArgs k = a;
     auto launch = [&](auto kernel) {
       /* (the indexes of two distinct large tables can exceed the 64 KB default) */
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
       int grid = resident_blocks(kernel, lds);
+      if (a.blocks_per_cu == -1) {
+        /* the kernel picks its own occupancy, which needs exactly three workgroups per
+         * CU in flight and #CUs = 1 mod 3; otherwise everybody works */
+        int cus = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        }
+        const bool fits = (grid == 3 * cus) && (cus % 3 == 1) && (want_blocks >= grid) &&
+                          !(a.max_blocks > 0 && a.max_blocks < grid);
+        if (!fits) {
+          k.blocks_per_cu = 0;
+        }
+      }
       if (a.blocks_per_cu > 0) {
         /* the caller knows how little work there is: fewer resident waves per
          * SIMD shorten every history's serial chain (see launch_solve_tiled) */
@@ -889,7 +925,7 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       if (a.max_blocks > 0 && grid > a.max_blocks) {
         grid = a.max_blocks;
       }
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, a);
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, k);
     };
     /* (the scalar-flux tally is a compile-time property of a kernel: the default
      * instantiations carry no trace of it) */

@@ -965,14 +965,4 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   return launch_solve(c, kVariantEventSorted, stream);
 }
 
-int tiled_collision_blocks_per_cu(unsigned queued, int cus) {
-  /* A collider is a serial chain of ~10^3 collisions; with few of them the stage
-   * lasts one chain, and a chain runs faster the fewer waves share its SIMD
-   * (csp, per chain: 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two:
-   * profiles/r01f).  So a queue that fits one (two) workgroup(s) per CU gets
-   * exactly that many; anything larger fills the chip as usual (0). */
-  const unsigned lanes_per_block_row = (unsigned)cus * 256u;
-  return (queued <= lanes_per_block_row) ? 1 : (queued <= 2u * lanes_per_block_row) ? 2 : 0;
-}
-
 }  // namespace neutral
