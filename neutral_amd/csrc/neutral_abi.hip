@@ -236,8 +236,8 @@ neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_star
 void sync_soa() {
   if (!g.soa_valid && g.rec_valid && g.rec_owner) {
     /* order[] is free between solves: scratch for the inverse permutation */
-    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.order, g.rec_owner_view,
-                                             g.rec_count, g.stream));
+    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.id_in, g.tiled.order,
+                                             g.rec_owner_view, g.rec_count, g.stream));
     wait_for_stream();
   }
   g.soa_valid = true;
@@ -270,8 +270,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     HIP_CHECK(hipMalloc((void**)&t.susp_track, sizeof(double) * (cap ? cap : 1)));
   }
   if (grow) {
-    void* old[] = {t.order,   t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor,
-                   t.rec_in,  t.rec_out,       t.info_in,    t.info_out,    t.susp};
+    void* old[] = {t.order,  t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor, t.rec_in,
+                   t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out};
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -283,6 +283,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles) {
     HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
     HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.id_in, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.id_out, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
     HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));
@@ -625,7 +627,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       sync_soa(); /* a previous owner's pending write-back */
       drop_records();
       HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
-                                               g.tiled.tiles_x, g.tiled.tile_shift, x_off, y_off,
+                                               g.tiled.id_in, g.tiled.tiles_x, g.tiled.tile_shift, x_off, y_off,
                                                a.nparticles, g.stream));
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
@@ -733,8 +735,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
     if (pass_export) {
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
-      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.order, a.p, a.nparticles,
-                                               g.stream));
+      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
+                                               a.p, a.nparticles, g.stream));
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
 
@@ -774,8 +776,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                             g.ev_streamed, g.ev_collected, &passes));
       HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
       if (pass_export) {
-        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.order, a.p,
-                                                 a.nparticles, g.stream));
+        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
+                                                 a.p, a.nparticles, g.stream));
       }
       HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
       if (neutral::comm_nranks() > 1) {
@@ -794,6 +796,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     unsigned* swap_info = t.info_in;
     t.info_in = t.info_out;
     t.info_out = swap_info;
+    unsigned* swap_id = t.id_in;
+    t.id_in = t.id_out;
+    t.id_out = swap_id;
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
   }

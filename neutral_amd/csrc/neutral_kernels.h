@@ -153,6 +153,8 @@ struct TiledArgs {
    * of a strided read of the 80-B records. */
   unsigned* info_in;
   unsigned* info_out;
+  unsigned* id_in;         /* nparticles: particle id of each record (= rec.id, kept apart so */
+  unsigned* id_out;        /* that the export reads 4 bytes per record, not a 64-byte sector) */
   unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
                               the dead last; later passes: the migrants, into rec_out) */
   unsigned* tile_count;    /* ntiles + 2: histogram of the counting sort (zero between uses) */
@@ -215,11 +217,12 @@ hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const
 size_t tiled_lds_bytes(const SolveArgs& a);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 int tiles_x, int tile_shift, int x_off, int y_off, int n,
-                                 hipStream_t stream);
+                                 unsigned* ids, int tiles_x, int tile_shift, int x_off, int y_off,
+                                 int n, hipStream_t stream);
 /* slot_of_id: nparticles words of scratch (the sort's order[] array serves) */
-hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
-                                 const ParticleView& p, int n, hipStream_t stream);
+hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
+                                 unsigned* slot_of_id, const ParticleView& p, int n,
+                                 hipStream_t stream);
 /* tile edge (log2 cells) and window threshold for a problem; tiles and chunk capacity */
 int tiled_tile_shift(int nx, int ny, int nparticles, bool with_flux);
 int tiled_window_min_particles(int tile_shift);

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
     const unsigned src = t.order[j];
     t.rec_out[j] = t.rec_in[src];
     t.info_out[j] = t.info_in[src];
+    t.id_out[j] = t.id_in[src];
   }
 }
 
@@ -328,7 +329,8 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
 
 /* SoA store -> records, in id order */
 __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
-                                                                    unsigned* info, int tiles_x,
+                                                                    unsigned* info, unsigned* ids,
+                                                                    int tiles_x,
                                                                     int tile_shift, int x_off,
                                                                     int y_off, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
     r.id = (unsigned)i;
     r.dead = p.dead[i];
     rec[i] = r;
+    ids[i] = (unsigned)i;
     info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x,
                            tile_shift);
   }
@@ -355,12 +358,14 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
 /* records -> SoA store.  A direct scatter (each record to the eleven arrays at its
  * id) writes 8 or 4 bytes into eleven different 64-B sectors per particle; going
  * through the inverse permutation instead costs one scattered 4-B write per
- * particle, one random 80-B record read, and eleven fully coalesced stores. */
-__global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const ParticleRec* rec,
+ * particle, one random 80-B record read, and eleven fully coalesced stores.  The
+ * ids come from their own 4-byte array (written next to the records): read out of
+ * the 80-byte records they cost a 64-byte sector each (4.2 -> see DESIGN.md). */
+__global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const unsigned* ids,
                                                                 unsigned* slot_of_id, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   if (i < n) {
-    slot_of_id[rec[i].id] = (unsigned)i;
+    slot_of_id[ids[i]] = (unsigned)i;
   }
 }
 
@@ -636,6 +641,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             pid = (t.pass == 0) ? mine : (int)src; /* this history's slot in rec_out */
             load_record(h, a, (t.pass == 0) ? t.rec_in[src] : t.rec_out[src]);
             if (t.pass == 0) {
+              t.id_out[pid] = h.id; /* who lives in the slot: kept apart for the export */
+            }
+            if (t.pass == 0) {
               prologue<kSameTables>(h, a, ix);
             } else {
               resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
@@ -826,21 +834,22 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 int tiles_x, int tile_shift, int x_off, int y_off, int n,
-                                 hipStream_t stream) {
+                                 unsigned* ids, int tiles_x, int tile_shift, int x_off, int y_off,
+                                 int n, hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, p, rec, info, tiles_x, tile_shift, x_off, y_off,
-                       n);
+                       dim3(kSortBlock), 0, stream, p, rec, info, ids, tiles_x, tile_shift, x_off,
+                       y_off, n);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_export_records(const ParticleRec* rec, unsigned* slot_of_id,
-                                 const ParticleView& p, int n, hipStream_t stream) {
+hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
+                                 unsigned* slot_of_id, const ParticleView& p, int n,
+                                 hipStream_t stream) {
   if (n > 0) {
     const int grid = (n + kSortBlock - 1) / kSortBlock;
-    hipLaunchKernelGGL(invert_ids_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec, slot_of_id,
+    hipLaunchKernelGGL(invert_ids_kernel, dim3(grid), dim3(kSortBlock), 0, stream, ids, slot_of_id,
                        n);
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
                        slot_of_id, p, n);

@@ -1,16 +1,27 @@
 #!/bin/bash
 # Round profile of the default bench.py run (csp 400^2, 1e8 particles, tiled):
-#   bench JSON, rocprofv3 kernel-trace stats, separate FETCH_SIZE / WRITE_SIZE passes.
-# Usage on the GPU box: bash tools/profile_bench.sh <round-tag>
-R=$GRAFT_REPO_ROOT; tag=${1:-rXX}; out=$R/gpurun_out/$tag; mkdir -p $out
+#   the bench line itself, rocprofv3 kernel-trace stats of the same command, and the
+#   separate PMC passes that tools/pmc_events.py folds into profiles/pmc_per_event.json.
+# Usage on the GPU box: bash tools/profile_bench.sh <round-tag> [bench flags...]
+R=$GRAFT_REPO_ROOT; tag=${1:-rXX}; shift || true; out=$R/gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $out/bench.json 2> $out/bench.err; tail -c 600 $out/bench.json; echo
-rocprofv3 --kernel-trace --stats -d $out/ktrace --output-format csv -- python3 $R/bench.py --warmup 0 --no-cpu-baseline > $out/ktrace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 $R/bench.py --warmup 0 --no-cpu-baseline > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 $R/bench.py --warmup 0 --no-cpu-baseline > $out/pmc_write.log 2>&1
-# vector issue: wave-level VALU instructions (and the quarter-rate f64 ones), lane-cycles, and the
-# busy-clock counter that gives the effective shader clock of each kernel (MI355X_MICROARCH.md, DVFS)
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $out/pmc_valu --output-format csv -- python3 $R/bench.py --warmup 0 --no-cpu-baseline > $out/pmc_valu.log 2>&1
-python3 $R/tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write csp 400 100000000 2 $out/pmc_valu | tee $out/pmc_traffic.log
-cp $R/profiles/pmc_traffic.json $out/pmc_traffic.json
-cat $out/ktrace/*/*_kernel_stats.csv | cut -c1-150 | head -8
+python3 $R/bench.py "$@" > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.json; echo
+P="--warmup 0 --no-cpu-baseline --no-lazy-leg $*"
+python3 $R/bench.py $P > $out/bench_profiled_flags.json 2> $out/bench_profiled_flags.err
+rocprofv3 --kernel-trace --stats -d $out/ktrace --output-format csv -- python3 $R/bench.py $P > $out/ktrace.log 2>&1
+pass() { name=$1; shift; rocprofv3 --pmc "$@" -d $out/pmc_$name --output-format csv -- python3 $R/bench.py $P > $out/pmc_$name.log 2>&1; }
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+# wave-level vector instructions by class (what the issue roofline prices)
+pass valu SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
+# occupancy of the issue slots, lane utilisation, stalls, busy clock
+pass sq SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+python3 $R/tools/pmc_events.py --bench $out/bench_profiled_flags.json \
+  --source "tools/profile_bench.sh $tag: bench.py $P under rocprofv3 --pmc (4 passes)" \
+  $out/pmc_fetch $out/pmc_write $out/pmc_valu $out/pmc_sq | tee $out/pmc_per_event.log
+cp $R/profiles/pmc_per_event.json $out/pmc_per_event.json
+cat $out/ktrace/*/*_kernel_stats.csv | cut -c1-150 | head -12
+# the bench line again, now priced with this round's coefficients
+python3 $R/bench.py --no-cpu-baseline "$@" > $out/bench_priced.json 2> $out/bench_priced.err; tail -c 300 $out/bench_priced.json; echo
+# keep the raw per-dispatch CSVs out of the merge-back (tens of MB); summaries stay
+find $out -name "*_counter_collection.csv" -size +2M -delete
