@@ -2,8 +2,9 @@
 all:
 	python -c "import __graft_entry__ as g; g.build()"
 
+# the whole CPU suite, the five-minute scatter known answer included
 test-cpu: all
-	python -m pytest tests -x -q -m "not gpu"
+	NEUTRAL_FULL_KATS=1 python -m pytest tests -x -q -m "not gpu" 2>&1 | tee oracle/pins/full_kats.log
 
 test-gpu: all
 	python -m pytest tests -x -q -m gpu

@@ -327,9 +327,24 @@ def main():
     from neutral_amd import interface as iface
 
     iface.set_device(local_rank)
-    # the rank layer of the library: TCP rendezvous of the ranks (MASTER_ADDR, MASTER_PORT
-    # + 1), then RCCL on this rank's GPU with a time limit; a rank that cannot get RCCL up
-    # makes every rank stage the exchange through the host instead (reported below)
+    if world > 1 and "NEUTRAL_COMM_PORT" not in os.environ:
+        # the library's ranks meet on a TCP port of their own; rank 0 picks a free one and
+        # tells the others through the launcher's store at MASTER_ADDR:MASTER_PORT
+        # (PyTorch as plumbing only: no process group, no collective)
+        import socket
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                         int(os.environ.get("MASTER_PORT", "29500")), world, rank == 0,
+                         timeout=timedelta(seconds=120))
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                store.set("neutral_comm_port", str(sock.getsockname()[1]))
+        os.environ["NEUTRAL_COMM_PORT"] = store.get("neutral_comm_port").decode()
+    # the rank layer of the library: TCP rendezvous of the ranks, then RCCL on this rank's
+    # GPU with a time limit; a rank that cannot get RCCL up makes every rank stage the
+    # exchange through the host instead (reported below)
     transport = iface.comm_start() if world > 1 else iface.COMM_NONE
     lib = iface.library()
 

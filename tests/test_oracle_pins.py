@@ -139,17 +139,24 @@ def _default_deck_run(make_problem, cs, name):
     return _default_deck_runs[name]
 
 
-@pytest.mark.parametrize("name", ["stream", "csp", "scatter"])
+# scatter as shipped is 7e9 collisions -- five minutes on the eight cores of the build
+# container -- so it runs where the whole CPU suite is asked for (`make test-cpu` sets
+# NEUTRAL_FULL_KATS=1; last log: oracle/pins/full_kats.log); stream and csp always run
+LONG_KAT = pytest.mark.skipif(os.environ.get("NEUTRAL_FULL_KATS") != "1",
+                              reason="five minutes of CPU: `make test-cpu` (NEUTRAL_FULL_KATS=1)")
+DEFAULT_DECKS = ["stream", "csp", pytest.param("scatter", marks=[pytest.mark.fullkat, LONG_KAT])]
+
+
+@pytest.mark.parametrize("name", DEFAULT_DECKS)
 def test_reference_held__known_answers_default_decks(make_problem, cs, name):
     """problems/neutral.tests:1-3 at the decks' default sizes (4000^2 cells; 1e6, 1e6,
-    1e7 particles; 1, 10, 2 iterations), the reference's own tolerance.  scatter is
-    the long one: 7e9 collisions, about two minutes on eight cores."""
+    1e7 particles; 1, 10, 2 iterations), the reference's own tolerance."""
     tally, _, _ = _default_deck_run(make_problem, cs, name)
     expected = decks.KNOWN_ANSWERS[name]
     assert abs(tally - expected) / expected < decks.VALIDATE_TOLERANCE
 
 
-@pytest.mark.parametrize("name", ["stream", "csp", "scatter"])
+@pytest.mark.parametrize("name", DEFAULT_DECKS)
 def test_recorded_not_reproducible_here__omp3_default_decks(make_problem, cs, pins, name):
     """The omp3 backend's own output at the default sizes as the survey recorded it:
     exact event counts, tally to 1e-13."""
