@@ -293,9 +293,39 @@ int neutral_hip_comm_transport(void);
 /* sharding by inject_particles when there are several ranks (default 1); 0 leaves the
  * id range to the caller (neutral_hip_set_pid_base + its own particle count) */
 void neutral_hip_set_auto_shard(int on);
-/* particles in a sharded store created by inject_particles (this rank's share);
- * -1 for a store that was not sharded (one rank, or auto-shard off) */
+/* particles in a sharded or decomposed store created by inject_particles (this rank's
+ * share, or what is inside its block right now); -1 for any other store */
 int neutral_hip_store_count(const NeutralHipParticle* particles);
+/* ---- spatial domain decomposition (mesh too large to replicate) -------------------
+ * The reference has the plumbing only: rank offsets and neighbours in the interface
+ * (neutral_interface.h:13-15), PARTICLE_SENT (neutral_data.h:35), a
+ * send_and_mark_particle that is declared (omp3/neutral.h:63) and never defined; its
+ * facet_event walks off the local arrays (omp3/neutral.c:333-377) and its RNG key is
+ * the local array index (:89), so a decomposed run of it could not reproduce an
+ * undecomposed one.  Here: ranks_x x ranks_y ranks (= the ranks of the rank layer) own
+ * uniform blocks of the mesh; solve_transport_2d is called with the block's extent
+ * (nx, ny, x_off, y_off, arrays of the block: edges nx+1 / ny+1, density and tally
+ * nx*ny, pad = 0) and the global one (global_nx, global_ny).  A history that crosses
+ * into another rank's block stops on the facet, is sent there with its RNG counter,
+ * and goes on in the same timestep: rounds of exchange (RCCL send/recv; staged through
+ * the host otherwise) until no rank has a history in flight.  Keys are global particle
+ * ids, so every history is the one an undecomposed run computes, whichever ranks it
+ * visits; tallies are per block (validate sums them over the ranks).  Tiled variant
+ * only.
+ *   neutral_hip_set_decomposition  names the grid (after neutral_hip_comm_start) and
+ *       returns this rank's block; 0 on success, 1 if the grid does not match the ranks
+ *   neutral_hip_set_source_box     the GLOBAL source box (same numbers on every rank);
+ *   inject_particles(nparticles = N, ...) then makes a store with room for all N, holding
+ *       the particles the source puts into this rank's block; their number changes as
+ *       histories cross: solve_transport_2d writes it to *nlocal_particles, and
+ *       neutral_hip_store_count / neutral_hip_store_keys give it and the ids ([device],
+ *       keys[i] = id of the particle at index i of the arrays). */
+int neutral_hip_set_decomposition(int ranks_x, int ranks_y, int global_nx, int global_ny,
+                                  int* x_off, int* y_off, int* local_nx, int* local_ny);
+void neutral_hip_clear_decomposition(void);
+void neutral_hip_set_source_box(double left, double bottom, double width, double height);
+const unsigned* neutral_hip_store_keys(const NeutralHipParticle* particles);
+
 /* in-place sum over the ranks of n doubles in [device] memory, on hip_stream */
 void neutral_hip_comm_allreduce_f64(double* device_buf, size_t n, void* hip_stream);
 /* max over the ranks of a host scalar; barrier of the ranks (host side) */

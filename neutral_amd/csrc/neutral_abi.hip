@@ -121,7 +121,26 @@ struct State {
     const void* key; /* particles->x */
     int count;
     uint64_t first;
+    /* decomposed mesh: the store holds whatever particles are inside this rank's
+     * block right now -- `count` of `capacity` slots, keys[slot] = the particle's id */
+    bool decomposed;
+    int capacity;
+    unsigned* keys;
   };
+  /* spatial domain decomposition (neutral_hip_set_decomposition) */
+  bool domain_on = false;
+  neutral::DomainGrid domain = {1, 1, 0, 0};
+  double source_box[4] = {0.0, 0.0, 0.0, 0.0};
+  bool source_box_set = false;
+  unsigned* d_exchange = nullptr;    /* counts[64], offsets[64], cursors[64], 1 compaction cursor */
+  neutral::ParticleRec* d_send = nullptr;
+  neutral::ParticleRec* d_recv = nullptr;
+  size_t send_capacity = 0; /* records */
+  size_t recv_capacity = 0;
+  unsigned* rec_owner_keys = nullptr; /* keys[] of the mirrored store when it is decomposed */
+  unsigned* d_free_slots = nullptr;   /* slots emigrants left in this step (arrivals reuse them) */
+  size_t free_slots_capacity = 0;
+  int free_count = 0;
   Store stores[16] = {};
   int nstores = 0;
   double* d_step_tally = nullptr;
@@ -150,6 +169,7 @@ void ensure_scratch() {
   HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
   HIP_CHECK(hipMalloc((void**)&g.d_check, 4 * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
+  HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));
   g.tables.valid = false; /* its indexes live in the other device's scratch */
   HIP_CHECK(hipMalloc((void**)&g.d_index_fine,
                       sizeof(unsigned short) * (kMaxFineIndexBuckets + 1)));
@@ -235,9 +255,14 @@ neutral::CsIndex build_index(const double* d_keys, int n, unsigned short* d_star
  * Safe to call with any (or no) store in hand: the owner's arrays are remembered. */
 void sync_soa() {
   if (!g.soa_valid && g.rec_valid && g.rec_owner) {
-    /* order[] is free between solves: scratch for the inverse permutation */
-    HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.id_in, g.tiled.order,
-                                             g.rec_owner_view, g.rec_count, g.stream));
+    if (g.rec_owner_keys) { /* decomposed mesh: slot for slot */
+      HIP_CHECK(neutral::launch_export_by_slot(g.tiled.rec_in, g.rec_owner_view, g.rec_owner_keys,
+                                               g.rec_count, g.stream));
+    } else {
+      /* order[] is free between solves: scratch for the inverse permutation */
+      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.id_in, g.tiled.order,
+                                               g.rec_owner_view, g.rec_count, g.stream));
+    }
     wait_for_stream();
   }
   g.soa_valid = true;
@@ -251,9 +276,12 @@ void drop_records() {
 }
 
 /* (Re)allocates the tiled variant's workspace for this problem size. */
-void ensure_tiled_workspace(int nx, int ny, int nparticles) {
+void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
+  /* (a decomposed store can grow up to its capacity within a step: buffers are sized
+   * for that, the tile edge for what is there now) */
   int tx, ty, max_chunks;
-  const int shift = neutral::tiled_tile_shift(nx, ny, nparticles, g.flux_tally != nullptr);
+  const int shift = neutral::tiled_tile_shift(nx, ny, nparticles_now, g.flux_tally != nullptr);
+  const int nparticles = capacity > nparticles_now ? capacity : nparticles_now;
   neutral::tiled_geometry(nx, ny, nparticles, shift, &tx, &ty, &max_chunks);
   neutral::TiledArgs& t = g.tiled;
   const bool grow = nparticles > g.tiled_particles || tx * ty > g.tiled_tiles;
@@ -453,6 +481,86 @@ void exchange_step(const neutral::SolveArgs& a, double* tally) {
   }
 }
 
+/* Decomposed mesh, one round: this rank's emigrants (records of t.rec_out marked
+ * kRecEmigrate) go to the ranks that own the cells they crossed into; what arrives
+ * is appended behind the a.nparticles records already here, as migrants.  Returns the
+ * number of arrivals.  Collective over the ranks. */
+int exchange_particles(const neutral::SolveArgs& a, neutral::TiledArgs& t) {
+  const int n = neutral::comm_nranks();
+  const int me = neutral::comm_rank();
+  if (n > 64) {
+    fprintf(stderr, "libneutral_hip: the decomposed-mesh exchange handles up to 64 ranks.\n");
+    exit(EXIT_FAILURE);
+  }
+  unsigned* d_counts = g.d_exchange;
+  unsigned* d_offsets = g.d_exchange + 64;
+  unsigned* d_cursor = g.d_exchange + 128;
+  HIP_CHECK(hipMemsetAsync(g.d_exchange, 0, sizeof(unsigned) * 192, g.stream));
+  HIP_CHECK(neutral::launch_emigrant_count(t, a.nparticles, g.domain, d_counts, g.stream));
+  unsigned counts[64];
+  HIP_CHECK(hipMemcpyAsync(counts, d_counts, sizeof(unsigned) * (size_t)n, hipMemcpyDeviceToHost,
+                           g.stream));
+  wait_for_stream();
+  uint64_t matrix[64 * 64];
+  memset(matrix, 0, sizeof(uint64_t) * (size_t)n * n);
+  unsigned offsets[64];
+  size_t out = 0;
+  for (int d = 0; d < n; ++d) {
+    offsets[d] = (unsigned)out;
+    out += counts[d];
+    matrix[(size_t)me * n + d] = (uint64_t)counts[d] * sizeof(neutral::ParticleRec);
+  }
+  if (counts[me] != 0) {
+    fprintf(stderr, "libneutral_hip: rank %d: %u emigrants are bound for their own rank (the "
+                    "decomposition given to neutral_hip_set_decomposition does not match the "
+                    "mesh blocks passed to solve_transport_2d).\n", me, counts[me]);
+    exit(EXIT_FAILURE);
+  }
+  comms_allreduce_u64(matrix, (size_t)n * n, COMMS_SUM);
+  size_t in = 0;
+  for (int s2 = 0; s2 < n; ++s2) {
+    in += (size_t)(matrix[(size_t)s2 * n + me] / sizeof(neutral::ParticleRec));
+  }
+  if (out > g.send_capacity) {
+    if (g.d_send) HIP_CHECK(hipFree(g.d_send));
+    g.send_capacity = out + out / 2 + 1024;
+    HIP_CHECK(hipMalloc((void**)&g.d_send, sizeof(neutral::ParticleRec) * g.send_capacity));
+  }
+  if (in > g.recv_capacity) {
+    if (g.d_recv) HIP_CHECK(hipFree(g.d_recv));
+    g.recv_capacity = in + in / 2 + 1024;
+    HIP_CHECK(hipMalloc((void**)&g.d_recv, sizeof(neutral::ParticleRec) * g.recv_capacity));
+  }
+  if ((size_t)g.tiled_particles > g.free_slots_capacity) {
+    if (g.d_free_slots) HIP_CHECK(hipFree(g.d_free_slots));
+    g.free_slots_capacity = (size_t)g.tiled_particles;
+    HIP_CHECK(hipMalloc((void**)&g.d_free_slots, sizeof(unsigned) * g.free_slots_capacity));
+  }
+  /* the free list's length lives on the device next to the other exchange words */
+  unsigned* d_nfree = g.d_exchange + 193;
+  const unsigned nfree_now = (unsigned)g.free_count;
+  HIP_CHECK(hipMemcpyAsync(d_nfree, &nfree_now, sizeof(unsigned), hipMemcpyHostToDevice, g.stream));
+  HIP_CHECK(hipMemcpyAsync(d_offsets, offsets, sizeof(unsigned) * (size_t)n, hipMemcpyHostToDevice,
+                           g.stream));
+  HIP_CHECK(neutral::launch_emigrant_pack(t, a.nparticles, g.domain, d_offsets, d_cursor, g.d_send,
+                                          g.d_free_slots, d_nfree, g.stream));
+  g.free_count += (int)out;
+  neutral::comm_exchange_bytes(g.d_send, g.d_recv, matrix, g.stream);
+  g.host_syncs++;
+  /* arrivals take the slots emigrants left first, then slots behind the records */
+  const int reuse = ((int)in < g.free_count) ? (int)in : g.free_count;
+  const int grow = (int)in - reuse;
+  if ((size_t)a.nparticles + (size_t)grow > (size_t)g.tiled_particles) {
+    fprintf(stderr, "libneutral_hip: rank %d: %zu particles arrive but the store is full (%d "
+                    "slots).\n", me, in, g.tiled_particles);
+    exit(EXIT_FAILURE);
+  }
+  HIP_CHECK(neutral::launch_immigrant_append(t, g.d_recv, (int)in, a.nparticles, a.x_off, a.y_off,
+                                             g.d_free_slots, g.free_count, reuse, g.stream));
+  g.free_count -= reuse;
+  return grow;
+}
+
 const State::Store* find_store(const NeutralHipParticle* p) {
   for (int i = 0; i < g.nstores; ++i) {
     if (p && g.stores[i].key == (const void*)p->x) {
@@ -462,14 +570,16 @@ const State::Store* find_store(const NeutralHipParticle* p) {
   return nullptr;
 }
 
-void remember_store(const NeutralHipParticle* p, int count, uint64_t first) {
+State::Store* remember_store(const NeutralHipParticle* p, int count, uint64_t first) {
   const int slot = (g.nstores < 16) ? g.nstores++ : 15; /* (the oldest entries win) */
-  g.stores[slot] = State::Store{(const void*)p->x, count, first};
+  g.stores[slot] = State::Store{(const void*)p->x, count, first, false, count, nullptr};
+  return &g.stores[slot];
 }
 
 void forget_store(const NeutralHipParticle* p) {
   for (int i = 0; i < g.nstores; ++i) {
     if (g.stores[i].key == (const void*)p->x) {
+      if (g.stores[i].keys) HIP_CHECK(hipFree(g.stores[i].keys));
       g.stores[i] = g.stores[--g.nstores];
       return;
     }
@@ -527,6 +637,45 @@ void run_inject(const int nparticles, const int local_nx, const int local_ny, co
   HIP_CHECK(hipStreamSynchronize(g.stream));
 }
 
+/* decomposed mesh: this rank's part of the injected particles (see inject_particles) */
+void run_inject_filtered(State::Store* st, const int nparticles, const int local_nx,
+                         const int local_ny, const int pad, const double left_off,
+                         const double bottom_off, const double width, const double height,
+                         const int x_off, const int y_off, const double dt, const double* edgex,
+                         const double* edgey, const double initial_energy,
+                         const NeutralHipParticle* particles) {
+  ensure_scratch();
+  neutral::InjectArgs a;
+  a.nparticles = nparticles;
+  a.pid_base = 0;
+  a.local_nx = local_nx;
+  a.local_ny = local_ny;
+  a.pad = pad;
+  a.x_off = x_off;
+  a.y_off = y_off;
+  /* the global source box, if the caller named it (neutral_hip_set_source_box);
+   * otherwise the box passed in is taken to be it */
+  a.left_off = g.source_box_set ? g.source_box[0] : left_off;
+  a.bottom_off = g.source_box_set ? g.source_box[1] : bottom_off;
+  a.width = g.source_box_set ? g.source_box[2] : width;
+  a.height = g.source_box_set ? g.source_box[3] : height;
+  a.dt = dt;
+  a.initial_energy = initial_energy;
+  a.edgex = edgex;
+  a.edgey = edgey;
+  a.p = view_of(particles);
+  if (g.rec_owner == (const void*)particles->x) {
+    drop_records();
+    g.soa_valid = true;
+  }
+  unsigned kept = 0;
+  HIP_CHECK(neutral::launch_inject_filtered(a, st->keys, g.d_exchange + 192, g.stream));
+  HIP_CHECK(hipMemcpyAsync(&kept, g.d_exchange + 192, sizeof(unsigned), hipMemcpyDeviceToHost,
+                           g.stream));
+  HIP_CHECK(hipStreamSynchronize(g.stream));
+  st->count = (int)kept;
+}
+
 }  // namespace
 
 extern "C" {
@@ -551,11 +700,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   (void)reduce_array1;
   (void)reduce_array2;
 
-  if (!(*nlocal_particles)) {
+  if (!(*nlocal_particles) && neutral::comm_nranks() == 1) {
     printf("Out of particles\n"); /* omp3/neutral.c:30-33 */
     fflush(stdout);
     return;
   }
+  /* (with several ranks a rank without particles still takes part: the exchanges at
+   * the end of the step are collective, and on a decomposed mesh particles may arrive) */
   if (!particles || !particles->x || !particles->dead) {
     fprintf(stderr, "libneutral_hip: solve_transport_2d needs a particle store made by "
                     "this library's inject_particles (the dead[] array is required).\n");
@@ -586,10 +737,19 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.y_off = y_off;
   a.dt = dt;
   a.inv_ntotal_particles = 1.0 / (double)ntotal_particles; /* omp3/neutral.c:120 */
-  /* several ranks: the store holds this rank's shard (inject_particles made it so) */
-  const State::Store* shard = (neutral::comm_nranks() > 1) ? find_store(particles) : nullptr;
+  /* several ranks: the store holds this rank's shard (inject_particles made it so), or
+   * -- decomposed mesh -- the particles that are inside this rank's block right now */
+  State::Store* shard = const_cast<State::Store*>(find_store(particles));
+  const bool decomposed = shard && shard->decomposed;
+  if (!decomposed && neutral::comm_nranks() == 1) {
+    shard = nullptr;
+  }
+  if (decomposed && !tiled) {
+    fprintf(stderr, "libneutral_hip: a decomposed mesh needs the tiled variant.\n");
+    exit(EXIT_FAILURE);
+  }
   a.nparticles = shard ? shard->count : *nlocal_particles;
-  a.pid_base = shard ? shard->first : g.pid_base;
+  a.pid_base = decomposed ? 0 : (shard ? shard->first : g.pid_base);
   a.p = view_of(particles);
   a.density = density;
   a.edgex = edgex;
@@ -614,23 +774,32 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
    * and stays an experiment: NEUTRAL_HIP_FUSED_EXPORT=1. */
   const char* fused_env = getenv("NEUTRAL_HIP_FUSED_EXPORT");
   const bool fused_export = tiled && !g.lazy_export && fused_env && atoi(fused_env) != 0;
-  const bool pass_export = tiled && !g.lazy_export && !fused_export;
-  a.export_soa = fused_export ? 1 : 0;
+  const bool pass_export = tiled && !g.lazy_export && (!fused_export || decomposed);
+  a.export_soa = (fused_export && !decomposed) ? 1 : 0;
   a.export_view = nullptr;
+  a.decomposed = decomposed ? 1 : 0;
+  a.emigrants = nullptr;
   a.abort_flag = (const int*)g.d_check; /* low word of tables_check_kernel's verdict */
 
   if (tiled) {
-    ensure_tiled_workspace(nx, ny, a.nparticles);
+    ensure_tiled_workspace(nx, ny, a.nparticles, decomposed ? shard->capacity : 0);
     /* the records mirror one SoA store: (re)import when they are not current */
     if (!g.rec_valid || g.rec_owner != (const void*)particles->x ||
         g.rec_count != a.nparticles) {
       sync_soa(); /* a previous owner's pending write-back */
       drop_records();
-      HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
-                                               g.tiled.id_in, g.tiled.tiles_x, g.tiled.tile_shift, x_off, y_off,
-                                               a.nparticles, g.stream));
+      if (decomposed) {
+        HIP_CHECK(neutral::launch_import_by_slot(a.p, shard->keys, g.tiled, x_off, y_off,
+                                                 a.nparticles, g.stream));
+      } else {
+        HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
+                                                 g.tiled.id_in, g.tiled.tiles_x,
+                                                 g.tiled.tile_shift, x_off, y_off, a.nparticles,
+                                                 g.stream));
+      }
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
+      g.rec_owner_keys = decomposed ? shard->keys : nullptr;
       g.rec_count = a.nparticles;
       g.rec_valid = true;
     }
@@ -712,7 +881,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
 
     HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
-    const bool exchange = neutral::comm_nranks() > 1;
+    if (tiled) {
+      /* (the pipeline's control words are set by its own kernels -- unless there is
+       * nothing to launch them for: a rank that starts the step without particles) */
+      HIP_CHECK(hipMemsetAsync(g.tiled.ctrl, 0, sizeof(unsigned) * 8, g.stream));
+    }
+    /* (a decomposed mesh has nothing to sum: every rank tallies its own cells) */
+    const bool exchange = neutral::comm_nranks() > 1 && !decomposed;
     if (exchange) {
       a.tally = step_tally((size_t)nx * (size_t)ny);
       if (g.flux_tally) {
@@ -733,7 +908,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
     }
     HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
-    if (pass_export) {
+    if (pass_export && !decomposed) {
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
       HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
                                                a.p, a.nparticles, g.stream));
@@ -754,7 +929,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     wait_for_stream();
     /* (several ranks take every decision that leads to another exchange together:
      * the collectives must pair up) */
-    if (!any_rank(check[0] != 0)) {
+    if (!(decomposed ? check[0] != 0 : any_rank(check[0] != 0))) {
       break;
     }
     if (attempt >= 2) {
@@ -766,28 +941,82 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
 
   unsigned long long queue_total = ctrl[2];
   if (tiled) {
-    /* migrants left over: the step outran the plan (it needs more stream passes than
-     * the last one did).  More passes, as many again as have run; the histories they
-     * suspend get a collision stage of their own (the first one's are marked done),
-     * and with several ranks their tallies an exchange of their own. */
-    while (any_rank(ctrl[4] != 0)) {
-      neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
-      HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
-                                            g.ev_streamed, g.ev_collected, &passes));
-      HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
-      if (pass_export) {
-        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
-                                                 a.p, a.nparticles, g.stream));
+    const bool exchange = neutral::comm_nranks() > 1 && !decomposed;
+    /* Finishes what is enqueued: migrants left over mean the step outran the plan (it
+     * needs more stream passes than the last one did).  More passes, as many again as
+     * have run; the histories they suspend get a collision stage of their own (the
+     * first one's are marked done), and with several ranks their tallies an exchange
+     * of their own. */
+    auto finish_passes = [&]() {
+      while (exchange ? any_rank(ctrl[4] != 0) : (ctrl[4] != 0)) {
+        neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
+        HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
+                                              g.ev_streamed, g.ev_collected, &passes));
+        HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+        if (pass_export && !decomposed) {
+          HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
+                                                   a.p, a.nparticles, g.stream));
+        }
+        HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
+        if (exchange) {
+          exchange_step(a, energy_deposition_tally);
+        }
+        HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
+        HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
+                                 g.stream));
+        wait_for_stream();
+        queue_total += ctrl[2];
       }
-      HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
-      if (neutral::comm_nranks() > 1) {
-        exchange_step(a, energy_deposition_tally);
+    };
+    finish_passes();
+    if (decomposed) {
+      /* Decomposed mesh: histories that crossed into another rank's block wait as
+       * emigrants.  Rounds of: count and pack them by destination, exchange, append
+       * the arrivals, go on with the step for them -- until no rank has any. */
+      for (;;) {
+        uint64_t waiting = ctrl[7];
+        comms_allreduce_u64(&waiting, 1, COMMS_SUM);
+        if (waiting == 0) {
+          break;
+        }
+        const int arrived = exchange_particles(a, g.tiled);
+        a.nparticles += arrived;
+        neutral::TiledPlan more = {2, -1};
+        const int first = passes < 1 ? 1 : passes; /* (pass 0 would start histories over) */
+        HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, first, nullptr,
+                                              g.ev_streamed, g.ev_collected, &passes));
+        HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+        HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
+        HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
+        HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
+                                 g.stream));
+        wait_for_stream();
+        queue_total += ctrl[2];
+        finish_passes();
       }
-      HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
-      HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
+      /* the particles that are here now, without the holes the emigrants left; they
+       * land in the other record buffer, which is where the next step looks */
+      unsigned kept = 0;
+      g.free_count = 0; /* (the holes are closed: nothing to reuse next step) */
+      HIP_CHECK(neutral::launch_compact_records(g.tiled, a.nparticles, g.d_exchange + 192,
+                                                g.stream));
+      HIP_CHECK(hipMemcpyAsync(&kept, g.d_exchange + 192, sizeof(unsigned), hipMemcpyDeviceToHost,
+                               g.stream));
       wait_for_stream();
-      queue_total += ctrl[2];
+      shard->count = (int)kept;
+      *nlocal_particles = (int)kept;
+      g.rec_count = (int)kept;
+      if (pass_export) {
+        HIP_CHECK(neutral::launch_export_by_slot(g.tiled.rec_in, a.p, shard->keys, (int)kept,
+                                                 g.stream));
+        HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
+        wait_for_stream();
+      }
+      g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
+      g.soa_valid = !g.lazy_export;
     }
+  }
+  if (tiled && !decomposed) {
     /* this step's records become the next step's input */
     neutral::TiledArgs& t = g.tiled;
     neutral::ParticleRec* swap = t.rec_in;
@@ -887,7 +1116,8 @@ size_t inject_particles(const int nparticles, const int global_nx, const int loc
    * OpenMP static split of omp3/neutral.c:64-74 over ranks); ids stay global, so
    * every history is the one a single rank would run */
   int local = nparticles > 0 ? nparticles : 0;
-  const bool sharded = neutral::comm_nranks() > 1 && g.auto_shard;
+  const bool decomposed = g.domain_on && (local_nx < global_nx || g.domain.px * g.domain.py > 1);
+  const bool sharded = !decomposed && neutral::comm_nranks() > 1 && g.auto_shard;
   if (sharded) {
     long long first = 0, count = 0;
     comms_shard_range(local, neutral::comm_rank(), neutral::comm_nranks(), &first, &count);
@@ -910,6 +1140,22 @@ size_t inject_particles(const int nparticles, const int global_nx, const int loc
   *particles = p;
   if (sharded) {
     remember_store(p, local, g.pid_base);
+  }
+  if (decomposed) {
+    /* Decomposed mesh: the store has room for every particle of the problem (any of
+     * them may pass through this rank's block) and starts with the ones the source
+     * puts there.  `nparticles` and the particle box are the GLOBAL ones: every rank
+     * looks at all candidates, so that each particle is what one rank alone would
+     * have made of it. */
+    State::Store* st = remember_store(p, 0, 0);
+    st->decomposed = true;
+    st->capacity = local;
+    HIP_CHECK(hipMalloc((void**)&st->keys, sizeof(unsigned) * (n ? n : 1)));
+    allocation += sizeof(unsigned) * n;
+    run_inject_filtered(st, nparticles, local_nx, local_ny, pad, local_particle_left_off,
+                        local_particle_bottom_off, local_particle_width, local_particle_height,
+                        x_off, y_off, dt, edgex, edgey, initial_energy, p);
+    return allocation;
   }
 
   run_inject(local, local_nx, local_ny, pad, local_particle_left_off,
@@ -936,6 +1182,10 @@ void validate(const int nx, const int ny, const char* params_filename, const int
     global_energy_tally += h_tally[ii];
   }
   free(h_tally);
+  if (g.domain_on && neutral::comm_nranks() > 1) {
+    /* decomposed mesh: every rank holds the tally of its own cells (omp3/neutral.c:530) */
+    comms_allreduce_f64(&global_energy_tally, 1, COMMS_SUM);
+  }
 
   if (rank != 0) {
     return;
@@ -1077,6 +1327,13 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
                                     const double* edgey, const double initial_energy,
                                     NeutralHipParticle* particles) {
   const State::Store* st = find_store(particles);
+  if (st && st->decomposed) {
+    run_inject_filtered(const_cast<State::Store*>(st), st->capacity, local_nx, local_ny, pad,
+                        local_particle_left_off, local_particle_bottom_off, local_particle_width,
+                        local_particle_height, x_off, y_off, dt, edgex, edgey, initial_energy,
+                        particles);
+    return;
+  }
   if (st) {
     g.pid_base = st->first; /* this rank's shard, whatever count the caller names */
   }
@@ -1104,6 +1361,54 @@ void neutral_hip_invalidate_particles(NeutralHipParticle* particles) {
 void neutral_hip_set_scalar_flux_tally(double* device_tally) { g.flux_tally = device_tally; }
 
 void neutral_hip_set_auto_shard(int on) { g.auto_shard = on ? 1 : 0; }
+
+int neutral_hip_set_decomposition(int ranks_x, int ranks_y, int global_nx, int global_ny,
+                                  int* x_off, int* y_off, int* local_nx, int* local_ny) {
+  const int n = neutral::comm_nranks();
+  if (ranks_x < 1 || ranks_y < 1 || ranks_x * ranks_y != n || n > 64 ||
+      ranks_x > global_nx || ranks_y > global_ny) {
+    return 1;
+  }
+  g.domain.px = ranks_x;
+  g.domain.py = ranks_y;
+  g.domain.bx = (global_nx + ranks_x - 1) / ranks_x;
+  g.domain.by = (global_ny + ranks_y - 1) / ranks_y;
+  /* (every rank must own at least one column and one row of cells) */
+  if (g.domain.bx * (ranks_x - 1) >= global_nx || g.domain.by * (ranks_y - 1) >= global_ny) {
+    return 1;
+  }
+  g.domain_on = true;
+  const int r = neutral::comm_rank();
+  const int rx = r % ranks_x;
+  const int ry = r / ranks_x;
+  *x_off = rx * g.domain.bx;
+  *y_off = ry * g.domain.by;
+  *local_nx = (rx == ranks_x - 1) ? global_nx - *x_off : g.domain.bx;
+  *local_ny = (ry == ranks_y - 1) ? global_ny - *y_off : g.domain.by;
+  return 0;
+}
+
+void neutral_hip_clear_decomposition(void) {
+  g.domain_on = false;
+  g.domain = neutral::DomainGrid{1, 1, 0, 0};
+  g.source_box_set = false;
+}
+
+void neutral_hip_set_source_box(double left, double bottom, double width, double height) {
+  g.source_box[0] = left;
+  g.source_box[1] = bottom;
+  g.source_box[2] = width;
+  g.source_box[3] = height;
+  g.source_box_set = true;
+}
+
+const unsigned* neutral_hip_store_keys(const NeutralHipParticle* particles) {
+  const State::Store* st = find_store(particles);
+  if (st && st->decomposed && g.rec_owner == (const void*)particles->x) {
+    sync_soa(); /* (lazy export: the keys move with the arrays) */
+  }
+  return (st && st->decomposed) ? st->keys : nullptr;
+}
 
 int neutral_hip_store_count(const NeutralHipParticle* particles) {
   const State::Store* st = find_store(particles);

@@ -43,6 +43,11 @@ struct Rccl {
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  /* point to point, for the particle exchange of the decomposed-mesh mode (optional) */
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 struct Comm {
@@ -74,6 +79,10 @@ bool load_rccl(Rccl& r) {
   r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+  r.Send = (decltype(r.Send))dlsym(r.handle, "ncclSend");
+  r.Recv = (decltype(r.Recv))dlsym(r.handle, "ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.handle, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.handle, "ncclGroupEnd");
   return r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
 }
 
@@ -155,6 +164,49 @@ void comm_allreduce_sum(void* d_buf, size_t n, bool is_f64, hipStream_t stream) 
   }
   hip_or_die(hipMemcpyAsync(d_buf, h, n * 8, hipMemcpyHostToDevice, stream), "staging H2D");
   hip_or_die(hipStreamSynchronize(stream), "staging sync");
+}
+
+/* Personalised exchange of bytes in device memory (the particles that cross between
+ * the ranks' blocks of a decomposed mesh): rank s hands matrix[s * n + d] bytes to rank
+ * d, send buffer ordered by d, receive buffer ordered by s.  ncclSend / ncclRecv in one
+ * group over xGMI when RCCL is up, staged through the host otherwise.  Complete on
+ * return. */
+void comm_exchange_bytes(const void* d_send, void* d_recv, const uint64_t* matrix,
+                         hipStream_t stream) {
+  const int n = comm_nranks();
+  const int me = comm_rank();
+  size_t out = 0, in = 0;
+  for (int d = 0; d < n; ++d) out += (size_t)matrix[(size_t)me * n + d];
+  for (int s2 = 0; s2 < n; ++s2) in += (size_t)matrix[(size_t)s2 * n + me];
+  if (c.transport == NEUTRAL_HIP_COMM_RCCL && c.rccl.Send && c.rccl.Recv && c.rccl.GroupStart &&
+      c.rccl.GroupEnd) {
+    ncclResult_t r = c.rccl.GroupStart();
+    size_t so = 0, ro = 0;
+    for (int peer = 0; peer < n && r == ncclSuccess; ++peer) {
+      const size_t sb = (size_t)matrix[(size_t)me * n + peer];
+      const size_t rb = (size_t)matrix[(size_t)peer * n + me];
+      if (sb) r = c.rccl.Send((const char*)d_send + so, sb, ncclChar, peer, c.comm, stream);
+      if (rb && r == ncclSuccess) {
+        r = c.rccl.Recv((char*)d_recv + ro, rb, ncclChar, peer, c.comm, stream);
+      }
+      so += sb;
+      ro += rb;
+    }
+    if (r == ncclSuccess) r = c.rccl.GroupEnd();
+    if (r != ncclSuccess) {
+      fprintf(stderr, "libneutral_hip: rank %d: RCCL send/recv failed: %s\n", me,
+              c.rccl.GetErrorString(r));
+      exit(EXIT_FAILURE);
+    }
+    hip_or_die(hipStreamSynchronize(stream), "particle exchange");
+    return;
+  }
+  char* h = (char*)staging(out + in + 16);
+  if (out) hip_or_die(hipMemcpyAsync(h, d_send, out, hipMemcpyDeviceToHost, stream), "D2H");
+  hip_or_die(hipStreamSynchronize(stream), "particle exchange");
+  comms_alltoallv(h, h + out, matrix);
+  if (in) hip_or_die(hipMemcpyAsync(d_recv, h + out, in, hipMemcpyHostToDevice, stream), "H2D");
+  hip_or_die(hipStreamSynchronize(stream), "particle exchange");
 }
 
 }  // namespace neutral

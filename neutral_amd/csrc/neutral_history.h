@@ -398,6 +398,20 @@ __device__ __forceinline__ void store_particle(const History& h, const SolveArgs
   store_particle_view(h, a.p, pid);
 }
 
+constexpr int kRecStateBits = 3;
+/* The record's last word: its state in the low bits and, above them, the history's
+ * RNG counter -- what a history interrupted between two events needs beyond its
+ * particle fields to go on elsewhere (another pass, the collision stage, another
+ * rank) with the stream it would have had: omp3/neutral.c:131,235,294 count up from 0
+ * within a timestep. */
+__device__ __forceinline__ int record_word(int state, unsigned counter) {
+  return state | (int)(counter << kRecStateBits);
+}
+__device__ __forceinline__ int record_state(int word) { return word & ((1 << kRecStateBits) - 1); }
+__device__ __forceinline__ unsigned record_counter(int word) {
+  return (unsigned)word >> kRecStateBits;
+}
+
 __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r) {
   h.x = r.x;
   h.y = r.y;
@@ -411,6 +425,7 @@ __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, cons
   h.celly = r.celly;
   h.dead = 0;
   h.id = r.id;
+  h.counter = record_counter(r.dead); /* (prologue starts from 0 whatever this says) */
 }
 
 /* ParticleRec::dead doubles as the record's state inside a timestep */
@@ -419,14 +434,31 @@ enum RecState : int {
   kRecDead = 1,      /* omp3/neutral.c:91,245 */
   kRecCollide = 2,   /* suspended at a collision, waits for the collision kernel */
   kRecMigrate = 3,   /* left its tally window, waits for the next streaming pass */
+  /* spatial domain decomposition only (a rank that owns part of the mesh): */
+  kRecEmigrate = 4,  /* crossed into another rank's part of the mesh: waits to be sent */
+  kRecGone = 5,      /* sent: the slot is empty (dropped at the next sort) */
 };
+constexpr unsigned kSummaryTileMask = (1u << (32 - kRecStateBits)) - 1u;
 
-/* record summary: state in the top two bits, tile of the cell below (tiles of
- * 1 << tile_shift cells per edge: the tiled variant picks 16..128 per problem) */
+/* record summary: state in the top three bits, tile of the cell below (tiles of
+ * 1 << tile_shift cells per edge: the tiled variant picks 16..128 per problem).  An
+ * emigrant's cell lies outside the local mesh: its tile field is not used. */
 __device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x,
                                                  int tile_shift) {
-  return ((unsigned)state << 30) |
-         (unsigned)((celly >> tile_shift) * tiles_x + (cellx >> tile_shift));
+  return ((unsigned)state << (32 - kRecStateBits)) |
+         ((unsigned)((celly >> tile_shift) * tiles_x + (cellx >> tile_shift)) & kSummaryTileMask);
+}
+__device__ __forceinline__ int summary_state(unsigned summary) {
+  return (int)(summary >> (32 - kRecStateBits));
+}
+__device__ __forceinline__ unsigned summary_tile(unsigned summary) {
+  return summary & kSummaryTileMask;
+}
+
+/* spatial domain decomposition: is the history's cell outside this rank's mesh? */
+__device__ __forceinline__ bool outside_domain(const History& h, const SolveArgs& a) {
+  return ((unsigned)(h.cellx - a.x_off) >= (unsigned)a.nx) |
+         ((unsigned)(h.celly - a.y_off) >= (unsigned)a.ny);
 }
 
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
@@ -443,7 +475,7 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.cellx = h.cellx;
   o.celly = h.celly;
   o.id = h.id;
-  o.dead = state;
+  o.dead = record_word(state, h.counter);
   r = o;
 }
 
@@ -471,9 +503,10 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
 /* Re-derives the locals of a history that another kernel suspended at a loop
  * head after its streaming phase (no collision yet): the particle record holds
  * x, y, omega, energy, weight, cell AND the live dt_to_census / mfp_to_collision;
- * density, cross sections and speed are pure functions of those; exactly one
- * random draw (the prologue's) has been consumed and nothing is pending in the
- * deposition accumulator (every facet flushes it, omp3/neutral.c:325-327). */
+ * density, cross sections and speed are pure functions of those; the RNG counter
+ * travels in the record's last word (one draw, the prologue's, for a history that
+ * has only streamed) and nothing is pending in the deposition accumulator (every
+ * facet flushes it, omp3/neutral.c:325-327). */
 template <bool kSameTables, typename IndexPtr>
 __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
                                        const CsLookup<IndexPtr>& ix) {
@@ -485,7 +518,7 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   h.speed = speed_of(h.energy);
   h.energy_deposition = 0.0;
   h.track_length = 0.0;
-  h.counter = 1;
+  /* h.counter comes from the record as well: 1 for a history that has only streamed */
   h.nevents = 0;
   refresh_direction(h);
   refresh_deposition_terms<kSameTables>(h);
@@ -638,7 +671,10 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
  * profiles/r01g/ablate_facetloads.log).  Every value is computed from the same
  * operands as in the reference's order: the position update uses the direction
  * BEFORE a reflection, as :329-330 precede :333. */
-template <bool kCachedReciprocals = false, typename Tally>
+/* kDomain: may the neighbour cell belong to another rank (spatial decomposition)?
+ * 0 never, 1 always, 2 ask a.decomposed (wave-uniform; free in the collision stage,
+ * but six percent of the stream kernel, which therefore compiles both answers). */
+template <bool kCachedReciprocals = false, int kDomain = 2, typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
   /* step to the neighbour cell, or reflect at the outer boundary (:333-369), as
    * selects: the branch ladder of the reference costs ~35 scalar instructions of
@@ -658,8 +694,16 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 #if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
   const double new_density = h.local_density; /* timing experiment only (uniform decks) */
 #else
-  const double new_density =
-      *mesh_element(a.density, (ncelly - a.y_off) * a.nx + (ncellx - a.x_off));
+  int dens_x = ncellx - a.x_off;
+  int dens_y = ncelly - a.y_off;
+  if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
+    /* a rank that owns part of the mesh: the neighbour may be another rank's cell;
+     * read a cell of ours (the history stops here and is sent on: its caller checks
+     * outside_domain() before anything looks at the density) */
+    dens_x = (dens_x < 0) ? 0 : ((dens_x >= a.nx) ? a.nx - 1 : dens_x);
+    dens_y = (dens_y < 0) ? 0 : ((dens_y >= a.ny) ? a.ny - 1 : dens_y);
+  }
+  const double new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
 #endif
 
   const double distance_to_facet = h.distance;

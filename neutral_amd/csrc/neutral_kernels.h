@@ -138,6 +138,11 @@ struct SolveArgs {
   /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
    * eleven more array pointers (the collision stage): read where a history ends */
   const ParticleView* export_view;
+  /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,
+   * y_off + ny) of a larger mesh; a history that crosses out of them is stored as an
+   * emigrant instead of going on (0: the rank owns the whole mesh) */
+  int decomposed;
+  unsigned* emigrants; /* [device] their count (collision stage; the stream kernel has t.ctrl) */
   /* [device] non-zero: the host's cached view of the cs tables (identity, bucketed
    * indexes) no longer matches the tables; history kernels return at once and the
    * host re-runs the step with a fresh view (null: no cached view in use) */
@@ -148,7 +153,7 @@ struct SolveArgs {
 struct TiledArgs {
   ParticleRec* rec_in;     /* nparticles: last step's records (source of pass 0) */
   ParticleRec* rec_out;    /* nparticles: this step's records, in this step's tile order */
-  /* 4-B summary of each record, written with it: state << 30 | tile of its cell.
+  /* 4-B summary of each record, written with it: state << 29 | tile of its cell.
    * The counting sort and the collision queue are built from these 4 bytes instead
    * of a strided read of the 80-B records. */
   unsigned* info_in;
@@ -184,6 +189,13 @@ struct TiledArgs {
   int max_chunks;
 };
 
+/* spatial domain decomposition: px x py ranks, uniform blocks of bx x by cells (the
+ * last ones may be smaller); rank r owns block (r % px, r / px) */
+struct DomainGrid {
+  int px, py;
+  int bx, by;
+};
+
 /* what the host enqueues of a timestep of the tiled pipeline in one go */
 struct TiledPlan {
   int stream_passes; /* stream passes to enqueue back to back (steady state: what the
@@ -199,6 +211,12 @@ enum Variant {
 };
 
 hipError_t launch_inject(const InjectArgs& a, hipStream_t stream);
+/* decomposed mesh: every rank looks at all a.nparticles candidates (positions in the
+ * GLOBAL source box given by a.left_off ...) and keeps those that fall into its block
+ * of the mesh (a.edgex / a.edgey are the block's edges); keys[slot] = global id,
+ * *count = particles kept */
+hipError_t launch_inject_filtered(const InjectArgs& a, unsigned* keys, unsigned* count,
+                                  hipStream_t stream);
 hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
 /* *d_flag (device int) = 1 when the two tables are element-wise identical */
 hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
@@ -223,6 +241,25 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
                                  unsigned* slot_of_id, const ParticleView& p, int n,
                                  hipStream_t stream);
+/* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
+ * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
+ * behind the first_slot records, holes closed at the end of the step (t.rec_out ->
+ * t.rec_in; *cursor = records kept), and the slot-for-slot exchange with the SoA store */
+hipError_t launch_emigrant_count(const TiledArgs& t, int n, const DomainGrid& d, unsigned* counts,
+                                 hipStream_t stream);
+hipError_t launch_emigrant_pack(const TiledArgs& t, int n, const DomainGrid& d,
+                                const unsigned* offset, unsigned* cursor, ParticleRec* send,
+                                unsigned* free_slots, unsigned* nfree, hipStream_t stream);
+/* (the first `reuse` arrivals take the last entries of the free list of nfree slots) */
+hipError_t launch_immigrant_append(const TiledArgs& t, const ParticleRec* recv, int nrecv,
+                                   int first_slot, int x_off, int y_off,
+                                   const unsigned* free_slots, int nfree, int reuse,
+                                   hipStream_t stream);
+hipError_t launch_compact_records(const TiledArgs& t, int n, unsigned* cursor, hipStream_t stream);
+hipError_t launch_import_by_slot(const ParticleView& p, const unsigned* keys, const TiledArgs& t,
+                                 int x_off, int y_off, int n, hipStream_t stream);
+hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, unsigned* keys,
+                                 int n, hipStream_t stream);
 /* tile edge (log2 cells) and window threshold for a problem; tiles and chunk capacity */
 int tiled_tile_shift(int nx, int ny, int nparticles, bool with_flux);
 int tiled_window_min_particles(int tile_shift);

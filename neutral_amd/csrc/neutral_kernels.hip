@@ -104,6 +104,70 @@ __global__ __launch_bounds__(kBlock) void inject_kernel(InjectArgs a) {
   a.p.dead[kk] = 0;
 }
 
+/* cell of c in the block's edges, or -1 when c lies outside the block */
+__device__ __forceinline__ int find_cell_in_block(const double* __restrict__ edge, int n, double c) {
+  if (!(c >= edge[0]) || !(c < edge[n])) {
+    return -1;
+  }
+  return find_cell(edge, n, c);
+}
+
+/* spatial decomposition: the same particles as inject_kernel makes on one rank (same
+ * streams, same arithmetic: positions in the global source box), each kept by the rank
+ * whose block of the mesh it falls into */
+__global__ __launch_bounds__(kBlock) void inject_filtered_kernel(InjectArgs a, unsigned* keys,
+                                                                 unsigned* count) {
+  const long long kk = (long long)blockIdx.x * kBlock + threadIdx.x;
+  bool mine = false;
+  double px = 0.0, py = 0.0;
+  int cx = -1, cy = -1;
+  if (kk < a.nparticles) {
+    double rn0, rn1;
+    generate_random_numbers((uint64_t)kk, 0, 0, rn0, rn1); /* omp3/neutral.c:581 */
+    px = a.left_off + rn0 * a.width;
+    py = a.bottom_off + rn1 * a.height;
+    cx = find_cell_in_block(a.edgex + a.pad, a.local_nx, px);
+    cy = find_cell_in_block(a.edgey + a.pad, a.local_ny, py);
+    mine = (cx >= 0) & (cy >= 0);
+  }
+  const unsigned long long m = __ballot(mine);
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 0 && m) {
+    base = atomicAdd(count, (unsigned)__popcll(m));
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (mine) {
+    const unsigned slot = base + (unsigned)lane_rank(m);
+    double rn0, rn1;
+    generate_random_numbers((uint64_t)kk, 0, 1, rn0, rn1); /* omp3/neutral.c:611 */
+    const double theta = 2.0 * M_PI * rn0;
+    double s, c;
+    sincos(theta, &s, &c);
+    a.p.x[slot] = px;
+    a.p.y[slot] = py;
+    a.p.cellx[slot] = a.x_off + cx;
+    a.p.celly[slot] = a.y_off + cy;
+    a.p.omega_x[slot] = c;
+    a.p.omega_y[slot] = s;
+    a.p.energy[slot] = a.initial_energy;
+    a.p.weight[slot] = 1.0;
+    a.p.dt_to_census[slot] = a.dt;
+    a.p.mfp_to_collision[slot] = 0.0;
+    a.p.dead[slot] = 0;
+    keys[slot] = (unsigned)kk;
+  }
+}
+
+hipError_t launch_inject_filtered(const InjectArgs& a, unsigned* keys, unsigned* count,
+                                  hipStream_t stream) {
+  (void)hipMemsetAsync(count, 0, sizeof(unsigned), stream);
+  if (a.nparticles > 0) {
+    hipLaunchKernelGGL(inject_filtered_kernel, dim3((a.nparticles + kBlock - 1) / kBlock),
+                       dim3(kBlock), 0, stream, a, keys, count);
+  }
+  return hipGetLastError();
+}
+
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
 template <bool kSameTables, bool kFlux>
@@ -569,8 +633,17 @@ void history_regroup_kernel(SolveArgs a) {
         if (h.ev == kEvFacet) {
           nfacets++;
           cross_facet(h, a, tally);
-          next_event(true);
-          want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+          if (kQueue && a.decomposed && outside_domain(h, a)) {
+            /* into another rank's cells: the history waits to be sent (its RNG counter
+             * travels in the record) */
+            store_record(h, a, a.rec[pid], kRecEmigrate);
+            a.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, a.tiles_x, a.tile_shift);
+            atomicAdd(a.emigrants, 1u);
+            want = kWantRefill;
+          } else {
+            next_event(true);
+            want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+          }
         } else {
           if (h.ev == kEvCensus) {
             ncensus++;

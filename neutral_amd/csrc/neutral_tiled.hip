@@ -99,6 +99,7 @@ enum Ctrl : int {
   kCtrlMigrants = 4,   /* histories the last stream pass handed to the next one */
   kCtrlPassesUsed = 5, /* stream passes of this step that had work */
   kCtrlWindowed = 6,   /* chunks of this pass that stream under an LDS window */
+  kCtrlEmigrants = 7,  /* decomposed mesh: histories waiting to be sent to another rank */
 };
 /* A history of a chunk WITHOUT a window (a sparse tile, the small tail of a dense one)
  * runs on global atomics.  When other chunks of the pass do have windows it is handed
@@ -127,11 +128,13 @@ constexpr unsigned kNoBucket = 0xFFFFFFFFu;
  * in pass 0 the dead go to the last bucket (they are carried over behind the live
  * ones); in later passes everything else stays where it is */
 __device__ __forceinline__ unsigned sort_bucket(const TiledArgs& t, unsigned summary) {
-  const int state = (int)(summary >> 30);
+  const int state = summary_state(summary);
   if (t.pass == 0) {
-    return (state != kRecDead) ? (summary & 0x3FFFFFFFu) : (unsigned)t.ntiles;
+    /* (a slot whose particle was sent to another rank is not carried over at all) */
+    return (state == kRecGone) ? kNoBucket
+                               : (state != kRecDead) ? summary_tile(summary) : (unsigned)t.ntiles;
   }
-  return (state == kRecMigrate) ? (summary & 0x3FFFFFFFu) : kNoBucket;
+  return (state == kRecMigrate) ? summary_tile(summary) : kNoBucket;
 }
 
 /* the summaries a pass sorts: last step's in pass 0, this step's (written by the
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
   __shared__ unsigned s_base;
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
-  const bool susp = i < a.nparticles && (info[i] >> 30) == (unsigned)kRecCollide;
+  const bool susp = i < a.nparticles && summary_state(info[i]) == kRecCollide;
   const unsigned long long m = __ballot(susp);
   if ((threadIdx.x & 63) == 0) {
     s_count[wave] = (unsigned)__popcll(m);
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
     p.mfp_to_collision[k] = r.mfp_to_collision;
     p.cellx[k] = r.cellx;
     p.celly[k] = r.celly;
-    p.dead[k] = (r.dead == kRecDead) ? 1 : 0;
+    p.dead[k] = (record_state(r.dead) == kRecDead) ? 1 : 0;
   }
 }
 
@@ -482,6 +485,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
     t.ctrl[kCtrlMigrants] = 0;
     if (t.pass == 0) {
       t.ctrl[kCtrlPassesUsed] = 1;
+      t.ctrl[kCtrlEmigrants] = 0;
     } else if (nactive > 0) {
       t.ctrl[kCtrlPassesUsed] = (unsigned)t.pass + 1u;
     }
@@ -507,7 +511,7 @@ __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window,
   }
 }
 
-template <bool kSameTables, bool kFlux>
+template <bool kSameTables, bool kFlux, bool kDomain>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
   constexpr int kWindows = kFlux ? 2 : 1;
@@ -558,6 +562,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   unsigned w_processed = 0; /* per wave (uniform) */
   unsigned w_census = 0;
   unsigned w_migrants = 0;
+  unsigned w_emigrants = 0; /* histories that crossed into another rank's cells */
 
   History h;
   h.ev = kEvEnd;
@@ -648,6 +653,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             } else {
               resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
             }
+            if (!kDomain) {
+              /* a history in this kernel has drawn once (collisions happen elsewhere), and
+               * saying so keeps the counter out of the facet loop's registers; only a
+               * history that arrived from another rank can have collided already */
+              h.counter = 1;
+            }
             h.plain_div = 0;
             refresh_speed_reciprocal(h); /* no collision here: the speed stays */
             refresh_mfp_reciprocal(h);
@@ -684,7 +695,17 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               crossed = rep;
               break;
             }
-            cross_facet<true>(h, a, cell_tally); /* tallies the cell it leaves: this one */
+            /* (tallies the cell it leaves: this one) */
+            cross_facet<true, kDomain ? 1 : 0>(h, a, cell_tally);
+            if (kDomain) {
+              /* the neighbour cell may belong to another rank: the history stops on the
+               * facet, before anything of that cell (edges, density) is looked at */
+              if (outside_domain(h, a)) {
+                park = kRecEmigrate;
+                crossed = rep + 1;
+                break;
+              }
+            }
             decide<false>(h, a);
             /* (selects, then one exit test: the nested form costs ~15 more scalar
              * exec-mask instructions per facet) */
@@ -700,7 +721,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
            * dozen scalar instructions) */
           nfacets += (unsigned)crossed;
           h.nevents += (unsigned)crossed;
-          if (!windowed && budget_on && h.ev == kEvFacet && h.nevents >= kUnwindowedBudget) {
+          if (!windowed && budget_on && park == kRecIdle && h.ev == kEvFacet &&
+              h.nevents >= kUnwindowedBudget) {
             /* (h.nevents counts from the load of this pass: prologue and resume zero it) */
             const double ahead = h.speed * h.dt_to_census;
             if (ahead * (fabs(h.omega_x) * t.cells_per_x + fabs(h.omega_y) * t.cells_per_y) >
@@ -708,7 +730,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               park = kRecMigrate;
             }
           }
-          if (h.nevents > kMaxEventsPerHistory && h.ev == kEvFacet) {
+          if (h.nevents > kMaxEventsPerHistory && h.ev == kEvFacet && park == kRecIdle) {
             atomicAdd(&a.counters->aborted, 1u);
             h.ev = kEvEnd; /* ended like a history whose time has run out, next pass */
           }
@@ -739,6 +761,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         has = false;
       }
       w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
+      if (kDomain) {
+        w_emigrants += (unsigned)__popcll(__ballot(park == kRecEmigrate));
+      }
       w_census += (unsigned)__popcll(__ballot(did_census));
     }
   }
@@ -746,6 +771,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
    * word costs more than the streaming itself (one address takes ~100 adds/us) */
   if ((threadIdx.x & 63) == 0 && w_migrants) {
     atomicAdd(&t.ctrl[kCtrlMigrants], w_migrants);
+  }
+  if (kDomain && (threadIdx.x & 63) == 0 && w_emigrants) {
+    atomicAdd(&t.ctrl[kCtrlEmigrants], w_emigrants);
   }
   if (cur_tile >= 0) {
     flush_window<kW>(a, window, a.tally, win_ox, win_oy);
@@ -761,6 +789,218 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (w_census) atomicAdd(&a.counters->ncensus, (unsigned long long)w_census);
     }
   }
+}
+
+/* ---- 2b. spatial domain decomposition: what moves between ranks ----------------------
+ * A rank owns a block of the mesh (uniform blocks of bx x by cells over a px x py grid
+ * of ranks) and the particles inside it.  A history that crosses out of the block is
+ * stored as kRecEmigrate (stream kernel, collision stage); once the rank has nothing
+ * else to do, the emigrants are packed by destination, exchanged, appended at the
+ * receiver as migrants, and the step goes on there -- rounds repeat until no rank has
+ * emigrants.  The reference has only the plumbing of this (x_off / y_off / neighbours,
+ * neutral_interface.h:13-15; PARTICLE_SENT, neutral_data.h:35; send_and_mark_particle
+ * is declared, omp3/neutral.h:63, and never defined). */
+
+__device__ __forceinline__ int owner_rank(const DomainGrid& d, int cellx, int celly) {
+  int rx = cellx / d.bx;
+  int ry = celly / d.by;
+  rx = (rx < 0) ? 0 : ((rx >= d.px) ? d.px - 1 : rx);
+  ry = (ry < 0) ? 0 : ((ry >= d.py) ? d.py - 1 : ry);
+  return ry * d.px + rx;
+}
+
+/* counts[d] = emigrants bound for rank d */
+__global__ __launch_bounds__(kSortBlock) void emigrant_count_kernel(const ParticleRec* rec,
+                                                                    const unsigned* info, int n,
+                                                                    DomainGrid d, unsigned* counts) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < n && summary_state(info[i]) == kRecEmigrate) {
+    atomicAdd(&counts[owner_rank(d, rec[i].cellx, rec[i].celly)], 1u);
+  }
+}
+
+/* send[offset[d] + k] = the k-th emigrant bound for rank d, as a migrant; its slot is
+ * marked gone.  cursor[] starts at zero. */
+__global__ __launch_bounds__(kSortBlock) void emigrant_pack_kernel(ParticleRec* rec, unsigned* info,
+                                                                   int n, DomainGrid d,
+                                                                   const unsigned* offset,
+                                                                   unsigned* cursor,
+                                                                   ParticleRec* send, int tiles_x,
+                                                                   int tile_shift,
+                                                                   unsigned* free_slots,
+                                                                   unsigned* nfree) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < n && summary_state(info[i]) == kRecEmigrate) {
+    ParticleRec r = rec[i];
+    const int dest = owner_rank(d, r.cellx, r.celly);
+    const unsigned k = atomicAdd(&cursor[dest], 1u);
+    free_slots[atomicAdd(nfree, 1u)] = (unsigned)i; /* an arrival can have the slot */
+    const unsigned counter = record_counter(r.dead);
+    r.dead = record_word(kRecMigrate, counter);
+    send[offset[dest] + k] = r;
+    rec[i].dead = record_word(kRecGone, 0u);
+    info[i] = slot_summary(kRecGone, 0, 0, tiles_x, tile_shift);
+  }
+}
+
+/* arrivals take the slots emigrants left (the last `reuse` entries of the free list),
+ * then the slots behind the rank's records, and wait for the next pass */
+__global__ __launch_bounds__(kSortBlock) void immigrant_append_kernel(const ParticleRec* recv,
+                                                                      int nrecv, ParticleRec* rec,
+                                                                      unsigned* info, unsigned* ids,
+                                                                      int first_slot, int x_off,
+                                                                      int y_off, int tiles_x,
+                                                                      int tile_shift,
+                                                                      unsigned* migrants,
+                                                                      const unsigned* free_slots,
+                                                                      int nfree, int reuse) {
+  const int j = blockIdx.x * kSortBlock + threadIdx.x;
+  if (j == 0) {
+    atomicAdd(migrants, (unsigned)nrecv); /* the next pass has work: it looks at this count */
+  }
+  if (j < nrecv) {
+    const ParticleRec r = recv[j];
+    const int slot = (j < reuse) ? (int)free_slots[nfree - 1 - j] : first_slot + (j - reuse);
+    rec[slot] = r;
+    ids[slot] = r.id;
+    info[slot] = slot_summary(kRecMigrate, r.cellx - x_off, r.celly - y_off, tiles_x, tile_shift);
+  }
+}
+
+/* end of a step: the records that are still here, without the holes the emigrants
+ * left (order is whatever the atomics make it; nothing depends on it) */
+__global__ __launch_bounds__(kSortBlock) void compact_records_kernel(
+    const ParticleRec* rec, const unsigned* info, const unsigned* ids, int n, ParticleRec* rec_to,
+    unsigned* info_to, unsigned* ids_to, unsigned* cursor) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  const bool keep = i < n && summary_state(info[i]) != kRecGone;
+  const unsigned long long m = __ballot(keep);
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 0 && m) {
+    base = atomicAdd(cursor, (unsigned)__popcll(m));
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (keep) {
+    const unsigned j = base + (unsigned)lane_rank(m);
+    rec_to[j] = rec[i];
+    info_to[j] = info[i];
+    ids_to[j] = ids[i];
+  }
+}
+
+/* decomposed stores are exchanged with the SoA arrays slot for slot (a particle's
+ * index there is just where it happens to sit; its RNG key travels in keys[]) */
+__global__ __launch_bounds__(kSortBlock) void import_by_slot_kernel(ParticleView p,
+                                                                    const unsigned* keys,
+                                                                    ParticleRec* rec, unsigned* info,
+                                                                    unsigned* ids, int tiles_x,
+                                                                    int tile_shift, int x_off,
+                                                                    int y_off, int n) {
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  if (i < n) {
+    ParticleRec r;
+    r.x = p.x[i];
+    r.y = p.y[i];
+    r.omega_x = p.omega_x[i];
+    r.omega_y = p.omega_y[i];
+    r.energy = p.energy[i];
+    r.weight = p.weight[i];
+    r.dt_to_census = p.dt_to_census[i];
+    r.mfp_to_collision = p.mfp_to_collision[i];
+    r.cellx = p.cellx[i];
+    r.celly = p.celly[i];
+    r.id = keys[i];
+    r.dead = p.dead[i] ? kRecDead : kRecIdle;
+    rec[i] = r;
+    ids[i] = r.id;
+    info[i] = slot_summary(p.dead[i] ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off,
+                           tiles_x, tile_shift);
+  }
+}
+
+__global__ __launch_bounds__(kSortBlock) void export_by_slot_kernel(const ParticleRec* rec,
+                                                                    ParticleView p, unsigned* keys,
+                                                                    int n) {
+  const int k = blockIdx.x * kSortBlock + threadIdx.x;
+  if (k < n) {
+    const ParticleRec r = rec[k];
+    p.x[k] = r.x;
+    p.y[k] = r.y;
+    p.omega_x[k] = r.omega_x;
+    p.omega_y[k] = r.omega_y;
+    p.energy[k] = r.energy;
+    p.weight[k] = r.weight;
+    p.dt_to_census[k] = r.dt_to_census;
+    p.mfp_to_collision[k] = r.mfp_to_collision;
+    p.cellx[k] = r.cellx;
+    p.celly[k] = r.celly;
+    p.dead[k] = (record_state(r.dead) == kRecDead) ? 1 : 0;
+    keys[k] = r.id;
+  }
+}
+
+hipError_t launch_emigrant_count(const TiledArgs& t, int n, const DomainGrid& d, unsigned* counts,
+                                 hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(emigrant_count_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, t.rec_out, t.info_out, n, d, counts);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_emigrant_pack(const TiledArgs& t, int n, const DomainGrid& d,
+                                const unsigned* offset, unsigned* cursor, ParticleRec* send,
+                                unsigned* free_slots, unsigned* nfree, hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(emigrant_pack_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, t.rec_out, t.info_out, n, d, offset, cursor,
+                       send, t.tiles_x, t.tile_shift, free_slots, nfree);
+    /* the emigrants are on their way: the count starts over */
+    (void)hipMemsetAsync(&t.ctrl[kCtrlEmigrants], 0, sizeof(unsigned), stream);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_immigrant_append(const TiledArgs& t, const ParticleRec* recv, int nrecv,
+                                   int first_slot, int x_off, int y_off,
+                                   const unsigned* free_slots, int nfree, int reuse,
+                                   hipStream_t stream) {
+  if (nrecv > 0) {
+    hipLaunchKernelGGL(immigrant_append_kernel, dim3((nrecv + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, recv, nrecv, t.rec_out, t.info_out, t.id_out,
+                       first_slot, x_off, y_off, t.tiles_x, t.tile_shift, &t.ctrl[kCtrlMigrants],
+                       free_slots, nfree, reuse);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_records(const TiledArgs& t, int n, unsigned* cursor, hipStream_t stream) {
+  (void)hipMemsetAsync(cursor, 0, sizeof(unsigned), stream);
+  if (n > 0) {
+    hipLaunchKernelGGL(compact_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, t.rec_out, t.info_out, t.id_out, n, t.rec_in,
+                       t.info_in, t.id_in, cursor);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_import_by_slot(const ParticleView& p, const unsigned* keys, const TiledArgs& t,
+                                 int x_off, int y_off, int n, hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(import_by_slot_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, p, keys, t.rec_in, t.info_in, t.id_in, t.tiles_x,
+                       t.tile_shift, x_off, y_off, n);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, unsigned* keys,
+                                 int n, hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(export_by_slot_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, rec, p, keys, n);
+  }
+  return hipGetLastError();
 }
 
 /* ---- launcher ---------------------------------------------------------------------- */
@@ -884,16 +1124,17 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
                               (int)lds);
     hipLaunchKernelGGL(kernel, dim3(cus), dim3(kStreamBlock), lds, stream, a, t);
   };
-  if (a.flux_tally) {
-    if (a.same_tables) {
-      launch(stream_kernel<true, true>);
-    } else {
-      launch(stream_kernel<false, true>);
-    }
-  } else if (a.same_tables) {
-    launch(stream_kernel<true, false>);
-  } else {
-    launch(stream_kernel<false, false>);
+  /* (scalar flux and spatial decomposition are compile-time properties of the kernel:
+   * the default instantiation carries no trace of either) */
+  switch ((a.same_tables ? 4 : 0) | (a.flux_tally ? 2 : 0) | (a.decomposed ? 1 : 0)) {
+    case 7: launch(stream_kernel<true, true, true>); break;
+    case 6: launch(stream_kernel<true, true, false>); break;
+    case 5: launch(stream_kernel<true, false, true>); break;
+    case 4: launch(stream_kernel<true, false, false>); break;
+    case 3: launch(stream_kernel<false, true, true>); break;
+    case 2: launch(stream_kernel<false, true, false>); break;
+    case 1: launch(stream_kernel<false, false, true>); break;
+    default: launch(stream_kernel<false, false, false>); break;
   }
   return hipGetLastError();
 }
@@ -906,6 +1147,11 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     *passes_enqueued = first_pass;
   }
   if (a.nparticles <= 0) {
+    /* (a rank of a decomposed mesh whose block is empty right now; the caller still
+     * reads the events) */
+    if (after_sort && first_pass == 0) (void)hipEventRecord(after_sort, stream);
+    if (after_stream) (void)hipEventRecord(after_stream, stream);
+    if (after_collect) (void)hipEventRecord(after_collect, stream);
     return hipSuccess;
   }
   const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
@@ -965,6 +1211,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.tile_shift = t.tile_shift;
   c.susp = t.susp;
   c.susp_track = t.susp_track;
+  c.emigrants = &t.ctrl[kCtrlEmigrants];
   if (t.fine_index && c.same_tables) {
     c.scatter_index = t.fine_index;
     c.scatter_index_n = t.fine_index_n;

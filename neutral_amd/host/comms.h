@@ -34,6 +34,10 @@ void comms_bcast_bytes(void* buf, size_t n); /* from rank 0 */
 /* element-wise over the ranks, result everywhere, same bits everywhere (host arrays) */
 void comms_allreduce_f64(double* buf, size_t n, int op);
 void comms_allreduce_u64(uint64_t* buf, size_t n, int op);
+/* personalised exchange of bytes: rank s hands matrix[s * nranks + d] bytes to rank d
+ * (send buffer ordered by d, receive buffer ordered by s); the matrix is known on
+ * every rank */
+void comms_alltoallv(const void* sendbuf, void* recvbuf, const uint64_t* matrix);
 void comms_barrier(void);
 void initialise_comms(Mesh* mesh);
 void finalise_comms(void);

@@ -58,7 +58,7 @@ static void recv_all(int fd, void* buf, size_t n) {
   while (n) {
     const ssize_t k = recv(fd, p, n, 0);
     if (k <= 0) {
-      if (k < 0 && errno == EINTR) continue;
+      if (k < 0 && (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK)) continue;
       TERMINATE("rank %d: lost the connection to a peer while receiving (%s).\n", g_rank,
                 k == 0 ? "closed" : strerror(errno));
     }
@@ -134,6 +134,10 @@ void comms_start_from_env(void) {
         continue;
       }
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      /* (the accept timeout of the listening socket must not carry over: a rank may
+       * be silent for as long as its GPU is busy) */
+      struct timeval forever = {0, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &forever, sizeof(forever));
       int who = -1;
       recv_all(fd, &who, sizeof(who));
       if (who < 1 || who >= g_nranks || g_peer[who]) {
@@ -231,6 +235,70 @@ static void allreduce_words(void* buf, size_t n, int is_f64, int op) {
 
 void comms_allreduce_f64(double* buf, size_t n, int op) { allreduce_words(buf, n, 1, op); }
 void comms_allreduce_u64(uint64_t* buf, size_t n, int op) { allreduce_words(buf, n, 0, op); }
+
+/* Every rank s hands counts[d] bytes to every rank d (its send buffer holds them in
+ * order of d) and gets what the others hand to it, in order of s.  matrix[s * nranks + d]
+ * = bytes s sends to d, known on every rank (comms_allreduce_u64 of the rows).  Star
+ * through rank 0: the particle exchange of the decomposed-mesh mode when RCCL is not
+ * used -- emigrants per step are a boundary layer, not the bulk. */
+void comms_alltoallv(const void* sendbuf, void* recvbuf, const uint64_t* matrix) {
+  const int n = g_nranks;
+  if (n == 1) {
+    memcpy(recvbuf, sendbuf, (size_t)matrix[0]);
+    return;
+  }
+  if (g_rank != 0) {
+    size_t out = 0, in = 0;
+    for (int d = 0; d < n; ++d) out += (size_t)matrix[(size_t)g_rank * n + d];
+    for (int s2 = 0; s2 < n; ++s2) in += (size_t)matrix[(size_t)s2 * n + g_rank];
+    if (out) send_all(g_peer[0], sendbuf, out);
+    if (in) recv_all(g_peer[0], recvbuf, in);
+    return;
+  }
+  /* rank 0: everybody's send buffer, then everybody's receive buffer */
+  char** from = (char**)calloc((size_t)n, sizeof(char*));
+  size_t* off = (size_t*)calloc((size_t)n * n, sizeof(size_t)); /* of block (s, d) in from[s] */
+  for (int s2 = 0; s2 < n; ++s2) {
+    size_t total = 0;
+    for (int d = 0; d < n; ++d) {
+      off[(size_t)s2 * n + d] = total;
+      total += (size_t)matrix[(size_t)s2 * n + d];
+    }
+    if (s2 == 0) {
+      from[0] = (char*)sendbuf;
+    } else {
+      from[s2] = (char*)malloc(total ? total : 1);
+      if (!from[s2]) {
+        TERMINATE("rank 0: no memory to route %zu bytes.\n", total);
+      }
+      if (total) recv_all(g_peer[s2], from[s2], total);
+    }
+  }
+  for (int d = 0; d < n; ++d) {
+    char* to = (char*)recvbuf;
+    size_t total = 0;
+    for (int s2 = 0; s2 < n; ++s2) total += (size_t)matrix[(size_t)s2 * n + d];
+    if (d != 0) {
+      to = (char*)malloc(total ? total : 1);
+      if (!to) {
+        TERMINATE("rank 0: no memory to route %zu bytes.\n", total);
+      }
+    }
+    size_t at = 0;
+    for (int s2 = 0; s2 < n; ++s2) {
+      const size_t bytes = (size_t)matrix[(size_t)s2 * n + d];
+      memcpy(to + at, from[s2] + off[(size_t)s2 * n + d], bytes);
+      at += bytes;
+    }
+    if (d != 0) {
+      if (total) send_all(g_peer[d], to, total);
+      free(to);
+    }
+  }
+  for (int s2 = 1; s2 < n; ++s2) free(from[s2]);
+  free(from);
+  free(off);
+}
 
 void comms_barrier(void) {
   uint64_t token = 1;

@@ -9,12 +9,16 @@
  *
  *   neutral.hip <deck.params> [--set key=value ...] [--arch-params FILE]
  *               [--cs-dir DIR] [--tests FILE] [--variant 0|1|2] [--gpus N]
+ *               [--decompose PXxPY]
  *
  * --gpus N runs N ranks, one per GPU of this node: the driver forks them before
  * anything touches a GPU (ranks are ordinary processes that find each other through
  * RANK / WORLD_SIZE / MASTER_PORT, so any launcher that exports those -- torchrun
  * --no-python, for one -- does as well); particles are sharded, every rank holds
  * the mesh, and each timestep ends with one all-reduce of the tally (RCCL).
+ * --decompose PXxPY (PX * PY = N) cuts the MESH over the ranks instead: every rank
+ * holds one block of it and the particles inside; histories that cross between
+ * blocks are exchanged within the timestep (include/neutral_hip.h).
  *
  * --set overrides a scalar deck entry (nx, ny, nparticles, iterations, dt,
  * initial_energy): the BASELINE configurations are the shipped decks at other
@@ -164,6 +168,7 @@ int main(int argc, char** argv) {
   char keys[MAX_OVERRIDES][64];
   char values[MAX_OVERRIDES][64];
   int noverrides = 0;
+  int decompose_x = 0, decompose_y = 0;
   /* multi-process GPU work on this stack needs dmabuf IPC; read by the runtime at start-up */
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
   for (int i = 2; i + 1 < argc; ++i) {
@@ -194,6 +199,10 @@ int main(int argc, char** argv) {
       neutral_hip_set_tests_file(argv[++i]);
     } else if (strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) {
       ++i; /* handled above, before anything touched a GPU */
+    } else if (strcmp(argv[i], "--decompose") == 0 && i + 1 < argc) {
+      if (sscanf(argv[++i], "%dx%d", &decompose_x, &decompose_y) != 2) {
+        TERMINATE("--decompose wants PXxPY, e.g. 4x2\n");
+      }
     } else if (strcmp(argv[i], "--variant") == 0 && i + 1 < argc) {
       if (neutral_hip_set_variant(atoi(argv[++i]))) {
         TERMINATE("unknown --variant\n");
@@ -242,6 +251,19 @@ int main(int argc, char** argv) {
   }
   initialise_devices(mesh.rank); /* binds the rank to its GPU, starts the tally exchange */
   initialise_comms(&mesh);
+  if (decompose_x) {
+    /* this rank's block of the mesh instead of all of it */
+    int xo, yo, lx, ly;
+    if (neutral_hip_set_decomposition(decompose_x, decompose_y, mesh.global_nx, mesh.global_ny,
+                                      &xo, &yo, &lx, &ly)) {
+      TERMINATE("--decompose %dx%d does not fit %d rank(s) and a %d x %d mesh.\n", decompose_x,
+                decompose_y, mesh.nranks, mesh.global_nx, mesh.global_ny);
+    }
+    mesh.x_off = xo;
+    mesh.y_off = yo;
+    mesh.local_nx = lx + 2 * mesh.pad;
+    mesh.local_ny = ly + 2 * mesh.pad;
+  }
   initialise_mesh_2d(&mesh);
   SharedData shared_data = {0};
   initialise_shared_data_2d(mesh.local_nx, mesh.local_ny, mesh.pad, mesh.width, mesh.height,
@@ -254,18 +276,30 @@ int main(int argc, char** argv) {
   double edges[4];
   double* h = NULL;
   allocate_host_data(&h, 1);
-  double* d_edge[4] = {&mesh.edgex[mesh.x_off + mesh.pad], &mesh.edgey[mesh.y_off + mesh.pad],
-                       &mesh.edgex[nx + mesh.x_off + mesh.pad],
-                       &mesh.edgey[ny + mesh.y_off + mesh.pad]};
+  /* (the edge arrays hold this rank's edges: local indices) */
+  double* d_edge[4] = {&mesh.edgex[mesh.pad], &mesh.edgey[mesh.pad], &mesh.edgex[nx + mesh.pad],
+                       &mesh.edgey[ny + mesh.pad]};
   for (int k = 0; k < 4; ++k) {
     copy_buffer(1, &d_edge[k], &h, RECV);
     edges[k] = *h;
   }
   deallocate_host_data(h);
+  if (decompose_x) {
+    /* the library makes every rank look at all source particles and keep those of its
+     * block: it wants the source box of the whole mesh */
+    edges[0] = 0.0;
+    edges[1] = 0.0;
+    edges[2] = mesh.width;
+    edges[3] = mesh.height;
+  }
   NeutralSource src;
   neutral_source_from_deck(read_deck, mesh.width, mesh.height, edges[0], edges[1], edges[2],
                            edges[3], &src);
 
+  if (decompose_x) {
+    neutral_hip_set_source_box(src.local_particle_left_off, src.local_particle_bottom_off,
+                               src.local_particle_width, src.local_particle_height);
+  }
   double* tally = NULL;
   size_t allocation = allocate_data(&tally, (size_t)nx * (size_t)ny);
   NeutralHipParticle* particles = NULL;
@@ -276,6 +310,9 @@ int main(int argc, char** argv) {
                                    src.local_particle_bottom_off, src.local_particle_width,
                                    src.local_particle_height, mesh.x_off, mesh.y_off, mesh.dt,
                                    mesh.edgex, mesh.edgey, src.initial_energy, &particles);
+    if (decompose_x) {
+      nlocal = neutral_hip_store_count(particles); /* what the source put into this block */
+    }
   }
   if (master) {
     printf("Allocated %.4fGB of data.\n", allocation / GB); /* neutral_data.c:117 */

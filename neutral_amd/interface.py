@@ -84,7 +84,9 @@ ABI_SYMBOLS = (
     "neutral_hip_invalidate_particles", "neutral_hip_set_scalar_flux_tally",
     "neutral_hip_comm_start", "neutral_hip_comm_stop", "neutral_hip_comm_rank",
     "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_set_auto_shard",
-    "neutral_hip_store_count", "neutral_hip_comm_allreduce_f64", "neutral_hip_comm_max",
+    "neutral_hip_store_count", "neutral_hip_set_decomposition",
+    "neutral_hip_clear_decomposition", "neutral_hip_set_source_box", "neutral_hip_store_keys",
+    "neutral_hip_comm_allreduce_f64", "neutral_hip_comm_max",
     "neutral_hip_comm_barrier", "neutral_hip_bind_rank_device",
     "neutral_hip_comm_barrier_device", "neutral_hip_comm_selftest",
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
@@ -137,6 +139,11 @@ _lib.neutral_hip_comm_transport.restype = C.c_int
 _lib.neutral_hip_set_auto_shard.argtypes = [C.c_int]
 _lib.neutral_hip_store_count.restype = C.c_int
 _lib.neutral_hip_store_count.argtypes = [C.POINTER(Particle)]
+_lib.neutral_hip_set_decomposition.restype = C.c_int
+_lib.neutral_hip_set_decomposition.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
+_lib.neutral_hip_set_source_box.argtypes = [C.c_double] * 4
+_lib.neutral_hip_store_keys.restype = C.c_void_p
+_lib.neutral_hip_store_keys.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
 _lib.neutral_hip_comm_max.restype = C.c_double
 _lib.neutral_hip_comm_max.argtypes = [C.c_double]
@@ -342,7 +349,8 @@ class Simulation:
     """
 
     def __init__(self, problem, cs_keys, cs_values, device: int = 0, shard=None,
-                 cs_absorb=None, variant: Optional[int] = None, scalar_flux: bool = False):
+                 cs_absorb=None, variant: Optional[int] = None, scalar_flux: bool = False,
+                 domain=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -366,13 +374,33 @@ class Simulation:
         def dev(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
-        self.edgex, self.edgey = dev(problem.edgex), dev(problem.edgey)
-        self.edgedx, self.edgedy = dev(problem.edgedx), dev(problem.edgedy)
-        self.density = dev(problem.density)
-        self.tally = torch.zeros(problem.nx * problem.ny, dtype=torch.float64,
-                                 device=self.device)
+        # domain = (ranks_x, ranks_y): spatial decomposition over the ranks of the rank
+        # layer (comm_start first).  This rank then holds one block of the mesh -- its
+        # edges, density and tally -- and whatever particles are inside it.
+        self.domain = domain
+        self.x_off, self.y_off, self.lnx, self.lny = problem.x_off, problem.y_off, problem.nx, \
+            problem.ny
+        if domain is not None:
+            xo, yo, lx, ly = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            if _lib.neutral_hip_set_decomposition(domain[0], domain[1], problem.nx, problem.ny,
+                                                  C.byref(xo), C.byref(yo), C.byref(lx),
+                                                  C.byref(ly)) != 0:
+                raise ValueError(f"decomposition {domain} does not fit the ranks or the mesh")
+            self.x_off, self.y_off, self.lnx, self.lny = xo.value, yo.value, lx.value, ly.value
+            _lib.neutral_hip_set_source_box(problem.local_particle_left_off,
+                                            problem.local_particle_bottom_off,
+                                            problem.local_particle_width,
+                                            problem.local_particle_height)
+        bx = slice(self.x_off, self.x_off + self.lnx + 1)
+        by = slice(self.y_off, self.y_off + self.lny + 1)
+        self.edgex, self.edgey = dev(problem.edgex[bx]), dev(problem.edgey[by])
+        self.edgedx, self.edgedy = dev(problem.edgedx[bx]), dev(problem.edgedy[by])
+        block = np.asarray(problem.density).reshape(problem.ny, problem.nx)[
+            self.y_off:self.y_off + self.lny, self.x_off:self.x_off + self.lnx]
+        self.density = dev(block.ravel())
+        self.tally = torch.zeros(self.lnx * self.lny, dtype=torch.float64, device=self.device)
         # scalar-flux tally (include/neutral_hip.h): optional second mesh
-        self.flux = torch.zeros(problem.nx * problem.ny, dtype=torch.float64,
+        self.flux = torch.zeros(self.lnx * self.lny, dtype=torch.float64,
                                 device=self.device) if scalar_flux else None
         self._sk, self._sv = dev(cs_keys), dev(cs_values)
         if cs_absorb is None:
@@ -389,8 +417,8 @@ class Simulation:
 
     def _inject_args(self):
         p = self.p
-        return (p.nx, p.ny, p.pad, p.local_particle_left_off, p.local_particle_bottom_off,
-                p.local_particle_width, p.local_particle_height, p.x_off, p.y_off, p.dt,
+        return (self.lnx, self.lny, p.pad, p.local_particle_left_off, p.local_particle_bottom_off,
+                p.local_particle_width, p.local_particle_height, self.x_off, self.y_off, p.dt,
                 self.edgex.data_ptr(), self.edgey.data_ptr(), p.initial_energy)
 
     def inject(self):
@@ -402,12 +430,15 @@ class Simulation:
             self.particles, self.bytes_allocated = inject_particles(
                 self.n, p.nx, *self._inject_args())
             local = _lib.neutral_hip_store_count(self.particles)
-            if local >= 0:  # the library cut this rank's share
+            if local >= 0:  # the library cut this rank's share (or block)
                 self.n = local
                 self.pid_base = int(_lib.neutral_hip_get_pid_base())
                 self.nlocal = C.c_int(self.n)
         else:
             _lib.neutral_hip_reinject_particles(self.n, *self._inject_args(), self.particles)
+            if self.domain is not None:
+                self.n = _lib.neutral_hip_store_count(self.particles)
+                self.nlocal = C.c_int(self.n)
 
     def step(self, master_key: int) -> StepResult:
         p = self.p
@@ -420,14 +451,21 @@ class Simulation:
         _lib.neutral_hip_set_scalar_flux_tally(
             C.c_void_p(self.flux.data_ptr()) if self.flux is not None else None)
         solve_transport_2d(
-            p.nx - 2 * p.pad, p.ny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, p.x_off,
-            p.y_off, p.dt, p.nparticles, self.nlocal, None, self.particles,
+            self.lnx - 2 * p.pad, self.lny - 2 * p.pad, p.nx, p.ny, master_key, p.pad, self.x_off,
+            self.y_off, p.dt, p.nparticles, self.nlocal, None, self.particles,
             self.density.data_ptr(), self.edgex.data_ptr(), self.edgey.data_ptr(),
             self.edgedx.data_ptr(), self.edgedy.data_ptr(), self.cs_scatter,
             self.cs_absorb, self.tally.data_ptr(), None, None, None, facets, collisions)
         s = last_step()
+        if self.domain is not None:
+            self.n = self.nlocal.value  # histories crossed between the ranks' blocks
         return StepResult(int(s.nprocessed), facets.value, collisions.value, s.kernel_ms,
                           int(s.census), s)
+
+    def particle_keys(self) -> np.ndarray:
+        """Global ids of the particles of a decomposed store, in array order."""
+        ptr = _lib.neutral_hip_store_keys(self.particles)
+        return to_host(ptr, self.n, np.uint32)
 
     def particle_arrays(self):
         """Host copies of the SoA particle store."""
@@ -447,7 +485,7 @@ class Simulation:
         self.tally.zero_()
 
     def validate(self, params_filename: Optional[str] = None):
-        validate(self.p.nx, self.p.ny, params_filename or self.p.deck, 0,
+        validate(self.lnx, self.lny, params_filename or self.p.deck, _lib.neutral_hip_comm_rank(),
                  self.tally.data_ptr())
 
     def close(self):

@@ -57,6 +57,36 @@ int main(int argc, char** argv) {
   CHECK(counts[0] == (uint64_t)(nranks * (nranks - 1) / 2) && counts[1] == (uint64_t)nranks);
   CHECK(counts[2] == ((uint64_t)nranks << 40));
 
+  /* personalised exchange (the particle exchange of the decomposed-mesh mode): rank s
+   * hands (s + 2 d + 1) records of 80 bytes to rank d, each stamped with (s, d, k) */
+  {
+    uint64_t* m = (uint64_t*)calloc((size_t)nranks * nranks, sizeof(uint64_t));
+    size_t out = 0, in = 0;
+    for (int d = 0; d < nranks; ++d) {
+      m[(size_t)rank * nranks + d] = (uint64_t)(rank + 2 * d + 1) * 80u;
+      out += (size_t)m[(size_t)rank * nranks + d];
+    }
+    comms_allreduce_u64(m, (size_t)nranks * nranks, COMMS_SUM);
+    for (int s2 = 0; s2 < nranks; ++s2) in += (size_t)m[(size_t)s2 * nranks + rank];
+    int* sb = (int*)calloc(out / 4 + 1, 4);
+    int* rb = (int*)calloc(in / 4 + 1, 4);
+    size_t at = 0;
+    for (int d = 0; d < nranks; ++d) {
+      for (int k = 0; k < rank + 2 * d + 1; ++k, at += 20) {
+        sb[at] = rank; sb[at + 1] = d; sb[at + 2] = k;
+      }
+    }
+    comms_alltoallv(sb, rb, m);
+    at = 0;
+    for (int s2 = 0; s2 < nranks; ++s2) {
+      for (int k = 0; k < s2 + 2 * rank + 1; ++k, at += 20) {
+        CHECK(rb[at] == s2 && rb[at + 1] == rank && rb[at + 2] == k);
+      }
+    }
+    CHECK(at * 4 == in);
+    free(m); free(sb); free(rb);
+  }
+
   /* shards: contiguous, disjoint, covering, the first total % nranks one longer */
   const long long total = 100000007LL;
   long long next = 0;

@@ -69,3 +69,31 @@ def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, nranks, comm):
     assert abs(tn - t1) <= 1e-12 * abs(t1)
     assert many.count("Iteration") == 4          # one rank speaks
     assert f"{nranks} ranks, tally exchange over the host" in err
+
+
+@pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
+@pytest.mark.parametrize("nranks,grid", [(2, "2x1"), (4, "2x2")])
+def test_forked_ranks_with_a_decomposed_mesh(tmp_path, nranks, grid):
+    """`neutral.hip --gpus N --decompose PXxPY`: every rank holds a block of the mesh and
+    the particles inside it; histories cross between the blocks within the step.  Event
+    counts as in the one-rank run, exactly; the tally (summed over the blocks by
+    validate) to summation order."""
+    from neutral_amd import cs_table, decks
+    run = tmp_path / "arch" / "neutral"
+    (run / "problems").mkdir(parents=True)
+    (tmp_path / "arch" / "arch.params").write_text("width 1.0\nheight 1.0\nsim_end 100.0\n")
+    cs_table.write_files(str(run))
+    rel = os.path.join("problems", "csp.params")
+    decks.write_deck("csp", str(run / rel))
+    sets = []
+    for kv in ("nx=128", "ny=128", "nparticles=200001", "iterations=4", "dt=1.0e-6"):
+        sets += ["--set", kv]
+    one, _ = _run_driver(str(run), rel, sets)
+    env = {"NEUTRAL_HIP_SHARE_DEVICE": "1", "NEUTRAL_COMM_TIMEOUT": "60",
+           "NEUTRAL_HIP_COMM": "host"}
+    many, err = _run_driver(str(run), rel, sets + ["--gpus", str(nranks), "--decompose", grid],
+                            env)
+    f1, c1, p1, t1 = _numbers(one)
+    fn, cn, pn, tn = _numbers(many)
+    assert (f1, c1, p1) == (fn, cn, pn), (one[-1500:], many[-1500:])
+    assert abs(tn - t1) <= 1e-12 * abs(t1)
