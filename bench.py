@@ -441,7 +441,10 @@ def main():
             roofline = dict(dom["valu_issue"] or {"bound": "valu_issue", "kernel": dom["name"],
                                                   "achieved": None, "peak":
                                                   SIMD_CYCLES_PER_S / 1e9, "frac": None,
-                                                  "unit": "G SIMD issue cycles/s"})
+                                                  "unit": "G SIMD issue cycles/s",
+                                                  "kernel_ms_avg": dom["ms_per_launch"],
+                                                  "note": "no PMC coefficients committed for this "
+                                                          "deck / mesh (profiles/pmc_per_event.json)"})
             roofline["traffic"] = (dom.get("hbm") or {}).get("traffic_bytes_per_launch")
             roofline["hbm"] = {
                 "dominant_kernel": dom.get("hbm"),
