@@ -86,7 +86,6 @@ struct State {
   /* per-device scratch, created on first use */
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
-  int* d_flag = nullptr;
   unsigned long long* d_check = nullptr;            /* 4 words of tables_check_kernel */
   neutral::ParticleView* d_export_view = nullptr;   /* the stepped store's array pointers */
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
@@ -166,7 +165,6 @@ void ensure_scratch() {
   }
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
   HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
-  HIP_CHECK(hipMalloc((void**)&g.d_flag, sizeof(int)));
   HIP_CHECK(hipMalloc((void**)&g.d_check, 4 * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
   HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));

@@ -218,9 +218,6 @@ hipError_t launch_inject(const InjectArgs& a, hipStream_t stream);
 hipError_t launch_inject_filtered(const InjectArgs& a, unsigned* keys, unsigned* count,
                                   hipStream_t stream);
 hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
-/* *d_flag (device int) = 1 when the two tables are element-wise identical */
-hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
-                               const double* vb, int n, int* d_flag, hipStream_t stream);
 /* The host's cached view of the two cs tables, re-checked on the device every step:
  * out[0] = 1 unless hash(scatter keys) == expect_hash_s, hash(absorb keys) ==
  * expect_hash_a and (tables element-wise identical) == expect_same; out[1], out[2] =

@@ -8,7 +8,7 @@
  *   K2 history_regroup_kernel  persistent waves, lanes regrouped by next event;
  *                              also the collision stage of the tiled pipeline
  *   build_cs_index_kernel      exponent-bucketed index over a key array
- *   tables_equal_kernel        are the two cs tables the same data?
+ *   tables_check_kernel        are the cs tables still what the host's cached view says?
  *   probe_*                    unit access to the building blocks (known answers)
  *
  * Common ground: one work-item per history, 64-wide wavefronts, the whole
@@ -692,21 +692,7 @@ __global__ __launch_bounds__(kBlock) void build_cs_index_kernel(const double* ke
   start[b] = (unsigned short)s;
 }
 
-/* ---- table comparison ------------------------------------------------------ */
-
-__global__ __launch_bounds__(kBlock) void tables_equal_kernel(const double* ka, const double* va,
-                                                              const double* kb, const double* vb,
-                                                              int n, int* flag) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) {
-    /* bit comparison: NaNs and signed zeros must not compare "equal enough" */
-    const bool same = (__double_as_longlong(ka[i]) == __double_as_longlong(kb[i])) &&
-                      (__double_as_longlong(va[i]) == __double_as_longlong(vb[i]));
-    if (!same) {
-      atomicAnd(flag, 0);
-    }
-  }
-}
+/* ---- the cached view of the tables, re-checked every step ------------------------ */
 
 /* The host caches what it derived from the tables (identity, bucketed indexes) and
  * this kernel re-checks the cache on the device every step, so a caller that rewrites
@@ -1025,14 +1011,6 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     case 1: launch1(history_kernel<false, true>); break;
     default: launch1(history_kernel<false, false>); break;
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_tables_equal(const double* ka, const double* va, const double* kb,
-                               const double* vb, int n, int* d_flag, hipStream_t stream) {
-  const int grid = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(tables_equal_kernel, dim3(grid), dim3(kBlock), 0, stream, ka, va, kb, vb, n,
-                     d_flag);
   return hipGetLastError();
 }
 
