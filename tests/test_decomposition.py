@@ -123,3 +123,21 @@ def test_decomposed_run_with_the_scalar_flux(tmp_path, cs):
         assert [tuple(e) for e in r["events"]] == want_ev
     assert np.linalg.norm(got_t - want_t) / np.linalg.norm(want_t) < 1e-13
     assert np.linalg.norm(got_f - want_f) / np.linalg.norm(want_f) < 1e-13
+
+
+def test_sharded_ranks_with_the_scalar_flux(tmp_path, cs):
+    """Particle shards (the mesh replicated): energy tally AND scalar flux are all-reduced
+    per step, so every rank ends with both global meshes."""
+    from neutral_amd import decks
+    path = decks.write_deck("csp", str(tmp_path / "csp.params"), nx=100, ny=100, nparticles=30001,
+                            iterations=2, dt=1.0e-6)
+    want_p, want_t, want_f, want_ev, _ = _reference(path, cs, 2, flux=True)
+    ranks, _ = _run_ranks(path, str(tmp_path), 2, 3, 1, mode="shard", extra=("flux",))
+    assert sum(len(r["ids"]) for r in ranks) == 30001
+    for r in ranks:
+        assert [tuple(e) for e in r["events"]] == want_ev
+        assert np.linalg.norm(r["tally"].reshape(100, 100) - want_t) / np.linalg.norm(want_t) < 1e-12
+        assert np.linalg.norm(r["flux"].reshape(100, 100) - want_f) / np.linalg.norm(want_f) < 1e-12
+        k = r["ids"].astype(np.int64)
+        for f in FIELDS:
+            assert np.array_equal(r[f], want_p[f][k]), f

@@ -83,6 +83,18 @@ def test_every_tile_edge_gives_the_same_histories(iface, make_problem, cs, monke
     assert all(s.aborted == 0 for s in got[3])
 
 
+def test_meshes_with_more_tiles_than_the_sort_keeps_in_lds(iface, make_problem, cs, monkeypatch):
+    """1600^2 cells at a forced tile edge of 16 are 10 000 tiles: the counting sort places
+    with one global atomic per record instead of its LDS histogram (8 191 tiles at most)."""
+    prob = make_problem("stream", nx=1600, nparticles=20000, iterations=1)
+    want = _run(iface, prob, cs, 0, 1)
+    monkeypatch.setenv("NEUTRAL_TILE_CELLS", "16")
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "8")
+    got = _run(iface, prob, cs, 2, 1)
+    _same(want, got)
+    assert got[3][0].tile_cells == 16
+
+
 def test_tile_edge_follows_the_particle_density(iface, make_problem, cs):
     for deck, nx, n, want in (("csp", 100, 100000, 16), ("csp", 200, 100000, 32),
                               ("csp", 400, 100000, 64), ("stream", 1000, 20000, 128)):
