@@ -194,6 +194,13 @@ def hbm_view(deck, nx, variant, kernel, ev, launches, same_tables):
         out["traffic_bytes_per_launch"] = traffic / launches
         out["traffic_gbs"] = traffic / seconds / 1e9
         out["traffic_frac_of_hbm_peak"] = traffic / seconds / 1e9 / HBM_PEAK_GBS
+    if e is not None and n and e["per_event"].get("TCC_REQ_sum"):
+        c = e["per_event"]
+        hits, misses = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
+        if hits + misses > 0:
+            out["l2_hit_rate"] = hits / (hits + misses)
+        out["l2_requests_per_event"] = c["TCC_REQ_sum"]
+        out["l2_atomics_per_event"] = c.get("TCC_ATOMIC_sum", 0.0)
     return out
 
 

@@ -16,9 +16,11 @@ pass write WRITE_SIZE
 pass valu SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
 # occupancy of the issue slots, lane utilisation, stalls, busy clock
 pass sq SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+# L2: hits, misses, requests, atomics (L2 hit rate, atomic counts)
+pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum
 python3 $R/tools/pmc_events.py --bench $out/bench_profiled_flags.json \
-  --source "tools/profile_bench.sh $tag: bench.py $P under rocprofv3 --pmc (4 passes)" \
-  $out/pmc_fetch $out/pmc_write $out/pmc_valu $out/pmc_sq | tee $out/pmc_per_event.log
+  --source "tools/profile_bench.sh $tag: bench.py $P under rocprofv3 --pmc (5 passes)" \
+  $out/pmc_fetch $out/pmc_write $out/pmc_valu $out/pmc_sq $out/pmc_l2 | tee $out/pmc_per_event.log
 cp $R/profiles/pmc_per_event.json $out/pmc_per_event.json
 cat $out/ktrace/*/*_kernel_stats.csv | cut -c1-150 | head -12
 # the bench line again, now priced with this round's coefficients
