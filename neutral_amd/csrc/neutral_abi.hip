@@ -140,7 +140,8 @@ struct State {
   unsigned* d_free_slots = nullptr;   /* slots emigrants left in this step (arrivals reuse them) */
   size_t free_slots_capacity = 0;
   int free_count = 0;
-  Store stores[16] = {};
+  enum { kMaxStores = 64 };
+  Store stores[kMaxStores] = {};
   int nstores = 0;
   double* d_step_tally = nullptr;
   size_t step_tally_cells = 0;
@@ -270,6 +271,7 @@ void sync_soa() {
  * layout changes): the next tiled step imports it again. */
 void drop_records() {
   g.rec_valid = false;
+  g.free_count = 0; /* (slots emigrants left are holes of the records, not of the arrays) */
   g.plan_passes = 0;
 }
 
@@ -569,7 +571,12 @@ const State::Store* find_store(const NeutralHipParticle* p) {
 }
 
 State::Store* remember_store(const NeutralHipParticle* p, int count, uint64_t first) {
-  const int slot = (g.nstores < 16) ? g.nstores++ : 15; /* (the oldest entries win) */
+  if (g.nstores == State::kMaxStores) {
+    fprintf(stderr, "libneutral_hip: more than %d sharded particle stores alive at once "
+                    "(neutral_hip_free_particles releases one).\n", (int)State::kMaxStores);
+    exit(EXIT_FAILURE);
+  }
+  const int slot = g.nstores++;
   g.stores[slot] = State::Store{(const void*)p->x, count, first, false, count, nullptr};
   return &g.stores[slot];
 }
