@@ -82,20 +82,29 @@ def single(argv):
         sim.step(1)            # warm-up
         sim.inject()
         sim.zero_tally()
+        import time
+        import torch
         tot_ms = 0.0
+        export_ms = 0.0
         tot_steps = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         per = []
         stages = [0.0, 0.0, 0.0]
         for tt in range(1, its + 1):
             r = sim.step(tt)
             tot_ms += r.kernel_ms
+            export_ms += r.stats.export_ms
             tot_steps += r.particle_steps
             stages[0] += r.stats.sort_ms
             stages[1] += r.stats.stream_ms
             stages[2] += r.stats.collide_ms
             per.append(f"{r.kernel_ms:.1f}" + (f"/p{r.stats.stream_passes}" if r.stats.stream_passes > 1 else ""))
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
         tag = os.path.basename(os.environ.get("NEUTRAL_HIP_LIB", "default"))
         print(f"{tag:40s} {deck} nx={nx} n={n}: {tot_ms:9.1f} ms  {tot_steps / tot_ms / 1e6:8.3f} Gsteps/s"
+              f"  wall {wall_ms:.1f} ms (write-back pass {export_ms:.1f})"
               f"  tally={float(sim.tally.sum()):.6e}  sort/stream/collide "
               f"{stages[0]:.1f}/{stages[1]:.1f}/{stages[2]:.1f}  per-step ms: {' '.join(per)}",
               flush=True)
