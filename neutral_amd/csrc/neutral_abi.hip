@@ -109,6 +109,7 @@ struct State {
   /* what the last step of this record store needed: the next step is enqueued on that
    * assumption, without waiting for the device in between (0 / -1: nothing known) */
   int plan_passes = 0;
+  bool slots_valid = false;        /* tiled.slot_of_id describes tiled.rec_in */
 
   int host_syncs = 0;              /* waits for the device inside the current call */
   /* ranks: particle stores made by inject_particles (this rank's shards) and the
@@ -259,8 +260,12 @@ void sync_soa() {
       HIP_CHECK(neutral::launch_export_by_slot(g.tiled.rec_in, g.rec_owner_view, g.rec_owner_keys,
                                                g.rec_count, g.stream));
     } else {
-      /* order[] is free between solves: scratch for the inverse permutation */
-      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.id_in, g.tiled.order,
+      if (!g.slots_valid) { /* (the steps since kept the ids of the slots instead) */
+        HIP_CHECK(neutral::launch_invert_ids(g.tiled.id_in, g.tiled.slot_of_id, g.rec_count,
+                                             g.stream));
+        g.slots_valid = true;
+      }
+      HIP_CHECK(neutral::launch_export_records(g.tiled.rec_in, g.tiled.slot_of_id,
                                                g.rec_owner_view, g.rec_count, g.stream));
     }
     wait_for_stream();
@@ -300,7 +305,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   }
   if (grow) {
     void* old[] = {t.order,  t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor, t.rec_in,
-                   t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out};
+                   t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out,
+                   t.slot_of_id};
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -314,6 +320,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     HIP_CHECK(hipMalloc((void**)&t.info_out, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.id_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.id_out, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.slot_of_id, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
     HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));
@@ -807,10 +814,11 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                                  a.nparticles, g.stream));
       } else {
         HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
-                                                 g.tiled.id_in, g.tiled.tiles_x,
+                                                 g.tiled.slot_of_id, g.tiled.tiles_x,
                                                  g.tiled.tile_shift, x_off, y_off, a.nparticles,
                                                  g.stream));
       }
+      g.slots_valid = !decomposed; /* (the import lays the records out by id) */
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
       g.rec_owner_keys = decomposed ? shard->keys : nullptr;
@@ -839,6 +847,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                g.stream));
       a.export_view = g.d_export_view;
     }
+    g.tiled.slots_by_id = (pass_export && !decomposed) ? 1 : 0;
     g.tiled.cells_per_x = (double)nx / g.mesh_width;
     g.tiled.cells_per_y = (double)ny / g.mesh_height;
   } else {
@@ -930,8 +939,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         HIP_CHECK(neutral::launch_export_unless_done(g.tiled, a.p, a.nparticles, g.stream,
                                                      a.abort_flag));
       } else {
-        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
-                                                 a.p, a.nparticles, g.stream, a.abort_flag));
+        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.slot_of_id, a.p,
+                                                 a.nparticles, g.stream, a.abort_flag));
       }
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
@@ -979,8 +988,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
         if (pass_export && !decomposed) {
-          HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.id_out, g.tiled.order,
-                                                   a.p, a.nparticles, g.stream));
+          HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.slot_of_id, a.p,
+                                                   a.nparticles, g.stream));
         }
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {
@@ -1055,6 +1064,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     t.id_out = swap_id;
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
+    g.slots_valid = t.slots_by_id != 0;
   }
 
   float ms = 0.0f;

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "../host/comms.h"
 #include "neutral_comm.h"
@@ -56,6 +57,7 @@ struct Comm {
   Rccl rccl;
   ncclComm_t comm = nullptr;
   int device = 0;
+  bool first_collective_done = false;
   /* host staging buffer of the fallback transport */
   void* staging = nullptr;
   size_t staging_bytes = 0;
@@ -150,6 +152,32 @@ void comm_allreduce_sum(void* d_buf, size_t n, bool is_f64, hipStream_t stream) 
       fprintf(stderr, "libneutral_hip: rank %d: ncclAllReduce failed: %s\n", comm_rank(),
               c.rccl.GetErrorString(r));
       exit(EXIT_FAILURE); /* a rank that leaves takes the job down: no silent partial sums */
+    }
+    if (!c.first_collective_done) {
+      /* the first collective of a communicator is where a broken fabric shows: wait for
+       * it here, with a limit, and say so instead of hanging in some later wait */
+      const int limit_s = getenv("NEUTRAL_COMM_TIMEOUT") ? atoi(getenv("NEUTRAL_COMM_TIMEOUT")) : 120;
+      struct timespec t0, t;
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (;;) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) {
+          break;
+        }
+        if (q != hipErrorNotReady) {
+          hip_or_die(q, "the first RCCL all-reduce");
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if ((t.tv_sec - t0.tv_sec) > limit_s) {
+          fprintf(stderr, "libneutral_hip: rank %d: the first RCCL all-reduce did not finish within "
+                          "%d s; set NEUTRAL_HIP_COMM=host to stage the exchange through the "
+                          "hosts.\n", comm_rank(), limit_s);
+          _exit(EXIT_FAILURE);
+        }
+        struct timespec nap = {0, 200000};
+        nanosleep(&nap, nullptr);
+      }
+      c.first_collective_done = true;
     }
     return;
   }
@@ -303,6 +331,7 @@ void neutral_hip_comm_stop(void) {
     (void)c.rccl.CommDestroy(c.comm);
     c.comm = nullptr;
   }
+  c.first_collective_done = false;
   if (c.staging) {
     (void)hipHostFree(c.staging);
     c.staging = nullptr;

@@ -164,7 +164,14 @@ struct TiledArgs {
   unsigned* info_in;
   unsigned* info_out;
   unsigned* id_in;         /* nparticles: particle id of each record (= rec.id, kept apart so */
-  unsigned* id_out;        /* that the export reads 4 bytes per record, not a 64-byte sector) */
+  unsigned* id_out;        /* that a reader takes 4 bytes per record, not a 64-byte sector) */
+  unsigned* slot_of_id;    /* nparticles: where particle id's record is -- what the write-back
+                              goes by */
+  int slots_by_id;         /* 1: the step is followed by the write-back, so the kernels that
+                              place a record (pass 0, copy_inactive) note slot_of_id[id] (a
+                              scattered 4-B store each, hidden in the stream kernel) instead
+                              of id_out[slot]; 0 (lazy write-back, decomposed stores): they
+                              note id_out, and whoever writes back inverts it first */
   unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
                               the dead last; later passes: the migrants, into rec_out) */
   unsigned* tile_count;    /* ntiles + 2: histogram of the counting sort (zero between uses) */
@@ -241,12 +248,14 @@ hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const
 size_t tiled_lds_bytes(const SolveArgs& a);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 unsigned* ids, int tiles_x, int tile_shift, int x_off, int y_off,
+                                 unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
                                  int n, hipStream_t stream);
-/* slot_of_id: nparticles words of scratch (the sort's order[] array serves) */
-hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
-                                 unsigned* slot_of_id, const ParticleView& p, int n,
-                                 hipStream_t stream, const int* abort_flag = nullptr);
+/* slot_of_id: where each id's record is (TiledArgs::slot_of_id) */
+hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
+                                 const ParticleView& p, int n, hipStream_t stream,
+                                 const int* abort_flag = nullptr);
+/* slot_of_id from the ids of the records (after steps that kept id_out instead) */
+hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream);
 /* the write-back after a collision stage that may have done it already (t.ctrl says) */
 hipError_t launch_export_unless_done(const TiledArgs& t, const ParticleView& p, int n,
                                      hipStream_t stream, const int* abort_flag);

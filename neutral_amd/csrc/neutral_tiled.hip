@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
 /* pass 0: the records that sit the step out (the dead) are carried over behind the
  * live ones, which the stream kernel writes in tile order */
 __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, TiledArgs t) {
+  if (a.abort_flag && *a.abort_flag) {
+    return; /* (an abandoned attempt leaves slot_of_id as the last finished step made it) */
+  }
   const unsigned first_inactive = t.tile_offset[t.ntiles];
   const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
   if (j < (unsigned)a.nparticles) {
@@ -303,7 +306,13 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
     r.dead &= ~kRecQueuedBit; /* (it may have died in the collision stage, a step ago) */
     t.rec_out[j] = r;
     t.info_out[j] = t.info_in[src];
-    t.id_out[j] = t.id_in[src];
+    if (a.decomposed) {
+      t.id_out[j] = t.id_in[src];
+    } else if (t.slots_by_id) {
+      t.slot_of_id[r.id] = j;
+    } else {
+      t.id_out[j] = r.id;
+    }
   }
 }
 
@@ -342,7 +351,8 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
 
 /* SoA store -> records, in id order */
 __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
-                                                                    unsigned* info, unsigned* ids,
+                                                                    unsigned* info,
+                                                                    unsigned* slot_of_id,
                                                                     int tiles_x,
                                                                     int tile_shift, int x_off,
                                                                     int y_off, int n) {
@@ -362,22 +372,21 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
     r.id = (unsigned)i;
     r.dead = p.dead[i];
     rec[i] = r;
-    ids[i] = (unsigned)i;
+    slot_of_id[i] = (unsigned)i;
     info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x,
                            tile_shift);
   }
 }
 
 /* records -> SoA store.  A direct scatter (each record to the eleven arrays at its
- * id) writes 8 or 4 bytes into eleven different 64-B sectors per particle; going
- * through the inverse permutation instead costs one scattered 4-B write per
- * particle, one random 80-B record read, and eleven fully coalesced stores.  The
- * ids come from their own 4-byte array (written next to the records): read out of
- * the 80-byte records they cost a 64-byte sector each (4.2 -> see DESIGN.md). */
+ * id) writes 8 or 4 bytes into eleven different 64-B sectors per particle; going by
+ * id instead costs one scattered 4-B write per particle (slot_of_id, by the kernel that
+ * places the record: pass 0 of the stream kernel, copy_inactive, the import), one
+ * random 80-B record read, and eleven fully coalesced stores. */
 __global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const unsigned* ids,
                                                                 unsigned* slot_of_id, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  if (i < n && ids[i] < (unsigned)n) { /* (an aborted attempt leaves an older step's ids) */
+  if (i < n && ids[i] < (unsigned)n) {
     slot_of_id[ids[i]] = (unsigned)i;
   }
 }
@@ -673,7 +682,13 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             pid = (t.pass == 0) ? mine : (int)src; /* this history's slot in rec_out */
             load_record(h, a, (t.pass == 0) ? t.rec_in[src] : t.rec_out[src]);
             if (t.pass == 0) {
-              t.id_out[pid] = h.id; /* who lives in the slot: kept apart for the export */
+              /* who lives in the slot / where the particle lives: what the write-back (or a
+               * decomposed store's compaction) goes by, without reading 80-B records */
+              if (kDomain || !t.slots_by_id) {
+                t.id_out[pid] = h.id;
+              } else {
+                t.slot_of_id[h.id] = (unsigned)pid;
+              }
             }
             if (t.pass == 0) {
               prologue<kSameTables>(h, a, ix);
@@ -1101,25 +1116,31 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 unsigned* ids, int tiles_x, int tile_shift, int x_off, int y_off,
+                                 unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
                                  int n, hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, p, rec, info, ids, tiles_x, tile_shift, x_off,
+                       dim3(kSortBlock), 0, stream, p, rec, info, slot_of_id, tiles_x, tile_shift, x_off,
                        y_off, n);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
-                                 unsigned* slot_of_id, const ParticleView& p, int n,
-                                 hipStream_t stream, const int* abort_flag) {
+hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
+                                 const ParticleView& p, int n, hipStream_t stream,
+                                 const int* abort_flag) {
   if (n > 0) {
     const int grid = (n + kSortBlock - 1) / kSortBlock;
-    hipLaunchKernelGGL(invert_ids_kernel, dim3(grid), dim3(kSortBlock), 0, stream, ids, slot_of_id,
-                       n);
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
                        slot_of_id, p, n, (const unsigned*)nullptr, abort_flag);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(invert_ids_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
+                       0, stream, ids, slot_of_id, n);
   }
   return hipGetLastError();
 }
@@ -1127,9 +1148,8 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* ids,
 hipError_t launch_export_unless_done(const TiledArgs& t, const ParticleView& p, int n,
                                      hipStream_t stream, const int* abort_flag) {
   if (n > 0) {
-    /* (order[] still holds id -> slot from before the collision stage) */
     hipLaunchKernelGGL(export_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, t.rec_out, t.order, p, n,
+                       dim3(kSortBlock), 0, stream, t.rec_out, t.slot_of_id, p, n,
                        (const unsigned*)&t.ctrl[kCtrlOverlapOn], abort_flag);
   }
   return hipGetLastError();
@@ -1234,13 +1254,10 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.export_cursor = nullptr;
   c.overlap_on = nullptr;
   if (plan.overlap_export && a.export_view) {
-    /* the collision stage writes the finished records back while it collides: it needs
-     * id -> slot (order[] is free once the stream passes are done) and a cursor */
-    hipLaunchKernelGGL(invert_ids_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, t.id_out,
-                       t.order, a.nparticles);
+    /* the collision stage writes the finished records back while it collides */
     hipLaunchKernelGGL(decide_overlap_kernel, dim3(1), dim3(1), 0, stream, t.ctrl, a.nparticles,
                        plan.overlap_export == 2 ? 1 : 0);
-    c.export_slot_of_id = t.order;
+    c.export_slot_of_id = t.slot_of_id;
     c.export_cursor = &t.ctrl[kCtrlExportCursor];
     c.overlap_on = &t.ctrl[kCtrlOverlapOn];
   } else {

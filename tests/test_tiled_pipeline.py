@@ -216,6 +216,31 @@ def test_write_back_inside_the_collision_stage(iface, make_problem, cs, monkeypa
         assert not any(in_stage)
 
 
+def test_write_back_mode_can_change_between_steps(iface, make_problem, cs):
+    """Eager steps note where each particle's record is (slot_of_id), lazy steps note who
+    is in each slot (id_out, inverted when somebody asks for the arrays): switching
+    between them, and asking in between, always gives the arrays of variant 0."""
+    prob = make_problem("csp", nx=100, nparticles=40000, iterations=5, dt=1.0e-6)
+    ref = iface.Simulation(prob, *cs, variant=0)
+    sim = iface.Simulation(prob, *cs, variant=2)
+    ref.inject()
+    sim.inject()
+    try:
+        for tt, lazy, look in ((1, True, False), (2, False, True), (3, True, True),
+                               (4, True, False), (5, False, True)):
+            iface.set_lazy_export(lazy)
+            ref.step(tt)
+            sim.step(tt)
+            if look:
+                a, b = ref.particle_arrays(), sim.particle_arrays()
+                for f in a:
+                    assert np.array_equal(a[f], b[f]), (tt, f)
+    finally:
+        iface.set_lazy_export(False)
+        ref.close()
+        sim.close()
+
+
 def test_two_live_stores_under_lazy_export(iface, make_problem, cs):
     """The record workspace is shared: stepping a second, larger store must first
     write the first store's pending state back (round-1 advisor finding)."""
