@@ -798,6 +798,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.export_slot_of_id = nullptr;
   a.export_cursor = nullptr;
   a.overlap_on = nullptr;
+  a.export_skip_long_dead = 0;
   a.decomposed = decomposed ? 1 : 0;
   a.emigrants = nullptr;
   a.abort_flag = (const int*)g.d_check; /* low word of tables_check_kernel's verdict */
@@ -848,6 +849,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       a.export_view = g.d_export_view;
     }
     g.tiled.slots_by_id = (pass_export && !decomposed) ? 1 : 0;
+    /* (after a possible import / pending write-back above: are the arrays current now?) */
+    a.export_skip_long_dead = (pass_export && !decomposed && g.soa_valid) ? 1 : 0;
+    if (getenv("NEUTRAL_HIP_EXPORT_ALL")) a.export_skip_long_dead = 0; /* experiment knob */
     g.tiled.cells_per_x = (double)nx / g.mesh_width;
     g.tiled.cells_per_y = (double)ny / g.mesh_height;
   } else {
@@ -937,10 +941,11 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
       if (overlap_export) {
         HIP_CHECK(neutral::launch_export_unless_done(g.tiled, a.p, a.nparticles, g.stream,
-                                                     a.abort_flag));
+                                                     a.abort_flag, a.export_skip_long_dead != 0));
       } else {
-        HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.slot_of_id, a.p,
-                                                 a.nparticles, g.stream, a.abort_flag));
+        HIP_CHECK(neutral::launch_export_records(
+            g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, a.abort_flag,
+            a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
       }
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
@@ -988,8 +993,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
         if (pass_export && !decomposed) {
-          HIP_CHECK(neutral::launch_export_records(g.tiled.rec_out, g.tiled.slot_of_id, a.p,
-                                                   a.nparticles, g.stream));
+          HIP_CHECK(neutral::launch_export_records(
+              g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, nullptr,
+              a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
         }
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {

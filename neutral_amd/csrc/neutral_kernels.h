@@ -143,6 +143,8 @@ struct SolveArgs {
   const unsigned* export_slot_of_id;
   unsigned* export_cursor;
   const unsigned* overlap_on; /* [device] 1: this launch does the write-back (null: n/a) */
+  int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
+                                 since before it are left alone by the write-back pass */
   /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,
    * y_off + ny) of a larger mesh; a history that crosses out of them is stored as an
    * emigrant instead of going on (0: the rank owns the whole mesh) */
@@ -251,14 +253,19 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
                                  unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
                                  int n, hipStream_t stream);
 /* slot_of_id: where each id's record is (TiledArgs::slot_of_id) */
+/* first_inactive [device]: first slot of the particles that were dead when the step began --
+ * given when the arrays were current then, so that those are left alone; null: every record */
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream,
-                                 const int* abort_flag = nullptr);
+                                 const int* abort_flag = nullptr,
+                                 const unsigned* first_inactive = nullptr);
+const unsigned* tiled_first_inactive(const TiledArgs& t);
 /* slot_of_id from the ids of the records (after steps that kept id_out instead) */
 hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream);
 /* the write-back after a collision stage that may have done it already (t.ctrl says) */
 hipError_t launch_export_unless_done(const TiledArgs& t, const ParticleView& p, int n,
-                                     hipStream_t stream, const int* abort_flag);
+                                     hipStream_t stream, const int* abort_flag,
+                                     bool skip_long_dead);
 /* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
  * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
  * behind the first_slot records, holes closed at the end of the step (t.rec_out ->
