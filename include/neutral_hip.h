@@ -180,9 +180,6 @@ typedef struct {
   int tile_cells;       /* tiled variant: tile edge chosen for the problem (16..128 cells) */
   double export_ms;     /* tiled variant, default mode: HIP-event time of the write-back of
                            the records to the SoA arrays (not part of kernel_ms) */
-  int write_back_in_stage; /* 1: the collision stage did that write-back itself while it
-                           ran (its queue held 0.6..8 % of the particles), inside
-                           kernel_ms; the pass behind export_ms then found nothing to do */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

@@ -27,7 +27,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 5 /* 5: NeutralHipStepStats grew export_ms, write_back_in_stage; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 5 /* 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
@@ -110,7 +110,6 @@ struct State {
    * assumption, without waiting for the device in between (0 / -1: nothing known) */
   int plan_passes = 0;
   bool slots_valid = false;        /* tiled.slot_of_id describes tiled.rec_in */
-
   int host_syncs = 0;              /* waits for the device inside the current call */
   /* ranks: particle stores made by inject_particles (this rank's shards) and the
    * per-step tally that is all-reduced before it joins the caller's mesh */
@@ -790,14 +789,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   const bool pass_export = tiled && !g.lazy_export && (!fused_export || decomposed);
   a.export_soa = (fused_export && !decomposed) ? 1 : 0;
   a.export_view = nullptr;
-  const char* overlap_env = getenv("NEUTRAL_HIP_EXPORT_OVERLAP");
-  /* (the collision stage may do the write-back as a side job; whether it does is decided
-   * on the device, per step, from the length of its queue) */
-  const bool overlap_export = pass_export && !decomposed &&
-                              !(overlap_env && atoi(overlap_env) == 0);
-  a.export_slot_of_id = nullptr;
-  a.export_cursor = nullptr;
-  a.overlap_on = nullptr;
   a.export_skip_long_dead = 0;
   a.decomposed = decomposed ? 1 : 0;
   a.emigrants = nullptr;
@@ -842,7 +833,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       g.extent_nx = nx;
       g.extent_ny = ny;
     }
-    if (a.export_soa || overlap_export) {
+    if (a.export_soa) {
       /* the kernels read the store's array pointers from memory where a history ends */
       HIP_CHECK(hipMemcpyAsync(g.d_export_view, &a.p, sizeof(a.p), hipMemcpyHostToDevice,
                                g.stream));
@@ -862,8 +853,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
 
   neutral::StepCounters hc[2];
-  unsigned ctrl[16] = {0};
-  bool write_back_in_stage = false;
+  unsigned ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int passes = 0;
   int same = 0;
   for (int attempt = 0;; ++attempt) {
@@ -930,7 +920,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       neutral::TiledPlan plan;
       plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 2;
       plan.blocks_per_cu = -1; /* the collision stage sizes itself from its queue */
-      plan.overlap_export = !overlap_export ? 0 : (overlap_env && atoi(overlap_env) == 2) ? 2 : 1;
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, plan, 0, g.ev_sorted,
                                             g.ev_streamed, g.ev_collected, &passes));
     } else {
@@ -939,14 +928,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
     if (pass_export && !decomposed) {
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
-      if (overlap_export) {
-        HIP_CHECK(neutral::launch_export_unless_done(g.tiled, a.p, a.nparticles, g.stream,
-                                                     a.abort_flag, a.export_skip_long_dead != 0));
-      } else {
-        HIP_CHECK(neutral::launch_export_records(
-            g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, a.abort_flag,
-            a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
-      }
+      HIP_CHECK(neutral::launch_export_records(
+          g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, a.abort_flag,
+          a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
 
@@ -965,7 +949,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     /* (several ranks take every decision that leads to another exchange together:
      * the collectives must pair up) */
     if (!(decomposed ? check[0] != 0 : any_rank(check[0] != 0))) {
-      write_back_in_stage = tiled && overlap_export && ctrl[9] != 0;
       break;
     }
     if (attempt >= 2) {
@@ -985,10 +968,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
      * of their own. */
     auto finish_passes = [&]() {
       while (exchange ? any_rank(ctrl[4] != 0) : (ctrl[4] != 0)) {
-        /* (the whole store is written back after these: a side job of the first
-         * collision stage has not seen what they change) */
-        neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1, 0};
-        write_back_in_stage = false;
+        neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
@@ -1021,7 +1001,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         }
         const int arrived = exchange_particles(a, g.tiled);
         a.nparticles += arrived;
-        neutral::TiledPlan more = {2, -1, 0};
+        neutral::TiledPlan more = {2, -1};
         const int first = passes < 1 ? 1 : passes; /* (pass 0 would start histories over) */
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, first, nullptr,
                                               g.ev_streamed, g.ev_collected, &passes));
@@ -1132,7 +1112,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.stream_passes_enqueued = tiled ? passes : 0;
   g.last.tile_cells = tiled ? (1 << g.tiled.tile_shift) : 0;
   g.last.export_ms = (double)ms_export;
-  g.last.write_back_in_stage = write_back_in_stage ? 1 : 0;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

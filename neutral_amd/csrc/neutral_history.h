@@ -399,24 +399,17 @@ __device__ __forceinline__ void store_particle(const History& h, const SolveArgs
 }
 
 constexpr int kRecStateBits = 3;
-/* bit above the state: the record went through the collision stage's queue this step
- * (set when the stream kernel suspends the history, kept by everything the collision
- * stage stores).  The collision stage writes such a history to the SoA arrays itself
- * when it ends; the write-back that runs inside the collision stage leaves it alone. */
-constexpr int kRecQueuedBit = 1 << kRecStateBits;
-constexpr int kRecCounterShift = kRecStateBits + 1;
 /* The record's last word: its state in the low bits and, above them, the history's
  * RNG counter -- what a history interrupted between two events needs beyond its
  * particle fields to go on elsewhere (another pass, the collision stage, another
  * rank) with the stream it would have had: omp3/neutral.c:131,235,294 count up from 0
  * within a timestep. */
-__device__ __forceinline__ int record_word(int state, unsigned counter, bool queued = false) {
-  return state | (queued ? kRecQueuedBit : 0) | (int)(counter << kRecCounterShift);
+__device__ __forceinline__ int record_word(int state, unsigned counter) {
+  return state | (int)(counter << kRecStateBits);
 }
 __device__ __forceinline__ int record_state(int word) { return word & ((1 << kRecStateBits) - 1); }
-__device__ __forceinline__ bool record_queued(int word) { return (word & kRecQueuedBit) != 0; }
 __device__ __forceinline__ unsigned record_counter(int word) {
-  return (unsigned)word >> kRecCounterShift;
+  return (unsigned)word >> kRecStateBits;
 }
 
 __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r) {
@@ -469,7 +462,7 @@ __device__ __forceinline__ bool outside_domain(const History& h, const SolveArgs
 }
 
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
-                                             ParticleRec& r, int state, bool queued = false) {
+                                             ParticleRec& r, int state) {
   ParticleRec o;
   o.x = h.x;
   o.y = h.y;
@@ -482,7 +475,7 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.cellx = h.cellx;
   o.celly = h.celly;
   o.id = h.id;
-  o.dead = record_word(state, h.counter, queued);
+  o.dead = record_word(state, h.counter);
   r = o;
 }
 

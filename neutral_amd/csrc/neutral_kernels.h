@@ -138,11 +138,6 @@ struct SolveArgs {
   /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
    * eleven more array pointers (the collision stage): read where a history ends */
   const ParticleView* export_view;
-  /* collision stage doing the write-back as a side job (neutral_kernels.hip): id ->
-   * record slot, and the cursor its waves take 64 ids at a time from (null: off) */
-  const unsigned* export_slot_of_id;
-  unsigned* export_cursor;
-  const unsigned* overlap_on; /* [device] 1: this launch does the write-back (null: n/a) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
                                  since before it are left alone by the write-back pass */
   /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,
@@ -216,10 +211,6 @@ struct TiledPlan {
                         last step needed plus one) */
   int blocks_per_cu; /* collision stage: workgroups per CU (0: as many as fit; -1: chosen by
                         the kernel from the queue length) */
-  int overlap_export; /* the collision stage may write the finished records back to the SoA
-                        arrays as a side job (decided on the device from its queue length);
-                        the write-back pass that follows then finds nothing to do.
-                        2: whatever the queue length (tests) */
 };
 
 enum Variant {
@@ -262,10 +253,6 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
 const unsigned* tiled_first_inactive(const TiledArgs& t);
 /* slot_of_id from the ids of the records (after steps that kept id_out instead) */
 hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream);
-/* the write-back after a collision stage that may have done it already (t.ctrl says) */
-hipError_t launch_export_unless_done(const TiledArgs& t, const ParticleView& p, int n,
-                                     hipStream_t stream, const int* abort_flag,
-                                     bool skip_long_dead);
 /* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
  * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
  * behind the first_slot records, holes closed at the end of the step (t.rec_out ->

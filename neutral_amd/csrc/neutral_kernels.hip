@@ -309,12 +309,11 @@ template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
-    store_record(h, a, a.rec[pid], state, true);
+    store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
-    if (a.export_view && (!a.overlap_on || *a.overlap_on)) {
-      /* the interface's arrays stay current (fused experiment, or this stage doing the
-       * write-back itself: see side_export_chunk).  The eleven array pointers are fetched
+    if (a.export_view) {
+      /* the interface's arrays stay current.  The eleven array pointers are fetched
        * here, from memory: as kernel arguments they would be live through the
        * collision loop and push it into scratch (100 B per lane, -20 %) */
       const ParticleView* pv = a.export_view;
@@ -324,65 +323,6 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
   } else {
     store_particle(h, a, pid);
   }
-}
-
-/* ---- the write-back, inside the collision stage ------------------------------------
- * The write-back of the records to the SoA arrays (a random 80-B read and eleven
- * coalesced stores per particle: 6.6 ms at 1e8 after 1.7 ms for id -> slot) can be done
- * by the waves of the collision stage themselves, a 64-id piece every few trips of their
- * loop, in registers that are free at the loop head.  Records the collision stage itself
- * works on (marked kRecQueuedBit) are skipped: it writes those to the arrays when their
- * history ends (put_back).  Whatever the loop has not done when a wave runs out of
- * collisions it does before it leaves.
- *
- * What it buys is modest and measured (profiles/r02/experiments/
- * write_back_in_collision_stage.log): the stage has no idle issue slots or registers to
- * hide the traffic in -- a wave that writes back is a wave that does not collide -- so it
- * lasts ~5 ms longer per 1e8 particles however the work is cut (cadence, several pieces
- * in flight, prefetched slots, non-temporal accesses: all within 1 %), against 6.6 ms
- * for the pass: -1.5 ms per step on the headline workload. */
-constexpr unsigned kExportGrab = 64 * 32; /* ids per reservation: an atomic per 64 ids on
-                                             the one cursor costs 20 ns each, serialised
-                                             (1e8 particles: +31 ms instead of -1.5) */
-constexpr unsigned kExportEvery = 4;      /* loop trips between pieces */
-__device__ __forceinline__ bool side_export_chunk(const SolveArgs& a, unsigned& next,
-                                                  unsigned& end) {
-  if (next >= end) {
-    unsigned base = 0;
-    if ((threadIdx.x & 63) == 0) {
-      base = atomicAdd(a.export_cursor, kExportGrab);
-    }
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= (unsigned)a.nparticles) {
-      return false; /* nothing left to write back */
-    }
-    next = base;
-    end = min(base + kExportGrab, (unsigned)a.nparticles);
-  }
-  const unsigned k = next + (threadIdx.x & 63);
-  next += 64;
-  if (k < (unsigned)a.nparticles) {
-    /* (the pass leaves particles alone that were dead when the step began; here the test
-     * costs more than it saves: +2 ms per 1e8 on the stage, measured) */
-    const ParticleRec r = a.rec[a.export_slot_of_id[k]];
-    if (!record_queued(r.dead)) {
-      const ParticleView* pv = a.export_view;
-      asm volatile("" : "+s"(pv)); /* (pointers fetched here, not held in registers) */
-      const ParticleView p = *pv;
-      p.x[k] = r.x;
-      p.y[k] = r.y;
-      p.omega_x[k] = r.omega_x;
-      p.omega_y[k] = r.omega_y;
-      p.energy[k] = r.energy;
-      p.weight[k] = r.weight;
-      p.dt_to_census[k] = r.dt_to_census;
-      p.mfp_to_collision[k] = r.mfp_to_collision;
-      p.cellx[k] = r.cellx;
-      p.celly[k] = r.celly;
-      p.dead[k] = (record_state(r.dead) == kRecDead) ? 1 : 0;
-    }
-  }
-  return true;
 }
 
 /* kQueue = false: variant 1, every particle of the SoA store, streamers and
@@ -505,14 +445,7 @@ void history_regroup_kernel(SolveArgs a) {
     drained = (share == 0);
   }
 
-  /* (wave-uniform; whether this launch does the write-back was decided on the device,
-   * from the length of its queue: decide_overlap_kernel) */
-  bool export_left = kQueue && a.export_slot_of_id != nullptr && *a.overlap_on != 0;
-  unsigned export_next = 0, export_end = 0, trip = 0;
   for (;;) {
-    if (kQueue && export_left && (trip++ % kExportEvery) == 0) {
-      export_left = side_export_chunk(a, export_next, export_end);
-    }
     const unsigned long long m_refill = __ballot(want == kWantRefill);
     const unsigned long long m_stream = __ballot(want == kWantStream);
     const unsigned long long m_collide = __ballot(want == kWantCollide);
@@ -671,7 +604,7 @@ void history_regroup_kernel(SolveArgs a) {
         const bool out = (want == kWantCollide);
         const unsigned long long m_out = __ballot(out);
         if (out) {
-          store_record(h, a, a.rec[pid], kRecCollide, true);
+          store_record(h, a, a.rec[pid], kRecCollide);
           SuspendExtra x;
           x.energy_deposition = h.energy_deposition;
           x.counter = h.counter;
@@ -703,7 +636,7 @@ void history_regroup_kernel(SolveArgs a) {
           if (kQueue && a.decomposed && outside_domain(h, a)) {
             /* into another rank's cells: the history waits to be sent (its RNG counter
              * travels in the record) */
-            store_record(h, a, a.rec[pid], kRecEmigrate, true);
+            store_record(h, a, a.rec[pid], kRecEmigrate);
             a.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, a.tiles_x, a.tile_shift);
             atomicAdd(a.emigrants, 1u);
             want = kWantRefill;
@@ -721,9 +654,6 @@ void history_regroup_kernel(SolveArgs a) {
         }
       }
     }
-  }
-  while (kQueue && export_left) {
-    export_left = side_export_chunk(a, export_next, export_end); /* what the loop left */
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
   if ((threadIdx.x & 63) == 0) {

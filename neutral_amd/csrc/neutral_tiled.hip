@@ -100,17 +100,9 @@ enum Ctrl : int {
   kCtrlPassesUsed = 5, /* stream passes of this step that had work */
   kCtrlWindowed = 6,   /* chunks of this pass that stream under an LDS window */
   kCtrlEmigrants = 7,  /* decomposed mesh: histories waiting to be sent to another rank */
-  kCtrlExportCursor = 8, /* write-back inside the collision stage: next id to write back */
-  kCtrlOverlapOn = 9,    /* 1: this step's collision stage does the write-back itself */
-  kCtrlFirstInactive = 10, /* first slot of the particles that were dead when the step began
-                              (pass 0 carries them over behind the live ones) */
+  kCtrlFirstInactive = 8, /* first slot of the particles that were dead when the step began
+                             (pass 0 carries them over behind the live ones) */
 };
-/* The collision stage takes the write-back along when it lasts long enough to hide it
- * (a queued history costs ~17 ns of the stage, a record ~0.07 ns of write-back: queue
- * >= 0.6 % of the particles) and its own histories -- which it writes to the arrays
- * with scattered stores -- are few (<= 8 %). */
-constexpr double kOverlapMinQueue = 0.006;
-constexpr double kOverlapMaxQueue = 0.08;
 /* A history of a chunk WITHOUT a window (a sparse tile, the small tail of a dense one)
  * runs on global atomics.  When other chunks of the pass do have windows it is handed
  * to the next pass after this many facet crossings (about one window's worth), like a
@@ -304,8 +296,7 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
   const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
   if (j < (unsigned)a.nparticles) {
     const unsigned src = t.order[j];
-    ParticleRec r = t.rec_in[src];
-    r.dead &= ~kRecQueuedBit; /* (it may have died in the collision stage, a step ago) */
+    const ParticleRec r = t.rec_in[src];
     t.rec_out[j] = r;
     t.info_out[j] = t.info_in[src];
     if (a.decomposed) {
@@ -393,24 +384,11 @@ __global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const unsigned* 
   }
 }
 
-__global__ void decide_overlap_kernel(unsigned* ctrl, int n, int force) {
-  const double queued = (double)ctrl[kCtrlCollideCount];
-  ctrl[kCtrlOverlapOn] =
-      (force || (queued >= kOverlapMinQueue * (double)n && queued <= kOverlapMaxQueue * (double)n))
-          ? 1u
-          : 0u;
-  ctrl[kCtrlExportCursor] = 0;
-}
-
 __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const ParticleRec* rec,
                                                                     const unsigned* slot_of_id,
                                                                     ParticleView p, int n,
-                                                                    const unsigned* done,
                                                                     const int* abort_flag,
                                                                     const unsigned* first_inactive) {
-  if (done && *done) {
-    return; /* the collision stage wrote the records back while it ran */
-  }
   if (abort_flag && *abort_flag) {
     return; /* the step's kernels have done nothing: rec holds an older step */
   }
@@ -795,7 +773,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           store_record(h, a, t.rec_out[pid], kRecIdle);
           t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
                                          t.tile_shift);
-          if (a.export_soa) {
+          if (a.export_view) {
             /* the interface's arrays stay current (pointers fetched here, not kept
              * in registers through the facet loop) */
             const ParticleView* pv = a.export_view;
@@ -808,7 +786,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       /* histories handed on: the record carries the state; migrants are counted */
       if (park != kRecIdle) {
-        store_record(h, a, t.rec_out[pid], park, park == kRecCollide);
+        store_record(h, a, t.rec_out[pid], park);
         t.info_out[pid] = slot_summary(park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
                                        t.tile_shift);
         has = false;
@@ -1143,7 +1121,7 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
   if (n > 0) {
     const int grid = (n + kSortBlock - 1) / kSortBlock;
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
-                       slot_of_id, p, n, (const unsigned*)nullptr, abort_flag, first_inactive);
+                       slot_of_id, p, n, abort_flag, first_inactive);
   }
   return hipGetLastError();
 }
@@ -1154,19 +1132,6 @@ hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, h
   if (n > 0) {
     hipLaunchKernelGGL(invert_ids_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
                        0, stream, ids, slot_of_id, n);
-  }
-  return hipGetLastError();
-}
-
-hipError_t launch_export_unless_done(const TiledArgs& t, const ParticleView& p, int n,
-                                     hipStream_t stream, const int* abort_flag,
-                                     bool skip_long_dead) {
-  if (n > 0) {
-    hipLaunchKernelGGL(export_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, t.rec_out, t.slot_of_id, p, n,
-                       (const unsigned*)&t.ctrl[kCtrlOverlapOn], abort_flag,
-                       skip_long_dead ? (const unsigned*)&t.ctrl[kCtrlFirstInactive]
-                                      : (const unsigned*)nullptr);
   }
   return hipGetLastError();
 }
@@ -1266,21 +1231,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   SolveArgs c = a;
   c.blocks_per_cu = plan.blocks_per_cu;
-  c.export_slot_of_id = nullptr;
-  c.export_cursor = nullptr;
-  c.overlap_on = nullptr;
-  if (plan.overlap_export && a.export_view) {
-    /* the collision stage writes the finished records back while it collides */
-    hipLaunchKernelGGL(decide_overlap_kernel, dim3(1), dim3(1), 0, stream, t.ctrl, a.nparticles,
-                       plan.overlap_export == 2 ? 1 : 0);
-    c.export_slot_of_id = t.slot_of_id;
-    c.export_cursor = &t.ctrl[kCtrlExportCursor];
-    c.overlap_on = &t.ctrl[kCtrlOverlapOn];
-  } else {
-    c.export_view = nullptr; /* (only the fused experiment keeps it without the side job) */
-    if (a.export_soa) {
-      c.export_view = a.export_view;
-    }
+  if (!a.export_soa) {
+    c.export_view = nullptr; /* (only the fused experiment stores where a history ends) */
   }
   {
     const char* force = getenv("NEUTRAL_K2_BLOCKS_PER_CU"); /* experiment knob */

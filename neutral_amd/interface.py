@@ -66,8 +66,7 @@ class StepStats(C.Structure):
                 ("aborted", C.c_uint64), ("stream_passes", C.c_int),
                 ("requeued", C.c_uint64), ("collide_passes", C.c_uint64),
                 ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
-                ("tile_cells", C.c_int), ("export_ms", C.c_double),
-                ("write_back_in_stage", C.c_int)]
+                ("tile_cells", C.c_int), ("export_ms", C.c_double)]
 
 
 # every symbol include/neutral_hip.h declares
