@@ -259,8 +259,8 @@ void sync_soa() {
       HIP_CHECK(neutral::launch_export_by_slot(g.tiled.rec_in, g.rec_owner_view, g.rec_owner_keys,
                                                g.rec_count, g.stream));
     } else {
-      if (!g.slots_valid) { /* (the steps since kept the ids of the slots instead) */
-        HIP_CHECK(neutral::launch_invert_ids(g.tiled.id_in, g.tiled.slot_of_id, g.rec_count,
+      if (!g.slots_valid) { /* (the steps since did not keep slot_of_id) */
+        HIP_CHECK(neutral::launch_invert_ids(g.tiled.rec_in, g.tiled.slot_of_id, g.rec_count,
                                              g.stream));
         g.slots_valid = true;
       }
@@ -811,6 +811,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                                  g.stream));
       }
       g.slots_valid = !decomposed; /* (the import lays the records out by id) */
+      g.tiled.sort_end = a.nparticles; /* (no graveyard yet) */
+      g.tiled.mirror_end = a.nparticles;
       g.rec_owner = (const void*)particles->x;
       g.rec_owner_view = a.p;
       g.rec_owner_keys = decomposed ? shard->keys : nullptr;
@@ -853,7 +855,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
 
   neutral::StepCounters hc[2];
-  unsigned ctrl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned ctrl[16] = {0};
   int passes = 0;
   int same = 0;
   for (int attempt = 0;; ++attempt) {
@@ -1051,6 +1053,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
     g.slots_valid = t.slots_by_id != 0;
+    /* the graveyard grows by what the sort carried over a step ago; what it carried over
+     * now joins next step (ctrl[8]: the first slot of the dead this step's sort found) */
+    t.mirror_end = t.sort_end;
+    t.sort_end = ((int)ctrl[8] <= t.sort_end) ? (int)ctrl[8] : t.sort_end;
   }
 
   float ms = 0.0f;

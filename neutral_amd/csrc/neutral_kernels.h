@@ -164,11 +164,21 @@ struct TiledArgs {
   unsigned* id_out;        /* that a reader takes 4 bytes per record, not a 64-byte sector) */
   unsigned* slot_of_id;    /* nparticles: where particle id's record is -- what the write-back
                               goes by */
+  /* The graveyard.  Records [sort_end, nparticles) belong to particles that were dead when
+   * the LAST step began: they keep their slots for good, in both record buffers, and take
+   * no part in the sort.  The dead of this step's sort are carried over to [first_inactive,
+   * sort_end) of rec_out by copy_inactive (and become graveyard next step); those carried
+   * over last step, [sort_end, mirror_end), are so far in rec_in only and are copied across
+   * once.  A dead particle thus costs two record copies, not one per step.  Decomposed
+   * stores (whose slot population changes within a step) keep sort_end = mirror_end =
+   * nparticles. */
+  int sort_end;
+  int mirror_end;
   int slots_by_id;         /* 1: the step is followed by the write-back, so the kernels that
                               place a record (pass 0, copy_inactive) note slot_of_id[id] (a
-                              scattered 4-B store each, hidden in the stream kernel) instead
-                              of id_out[slot]; 0 (lazy write-back, decomposed stores): they
-                              note id_out, and whoever writes back inverts it first */
+                              scattered 4-B store each, hidden in the stream kernel); 0: they
+                              do not (lazy write-back: whoever writes back reads the ids out
+                              of the records first; decomposed stores keep id_out[slot]) */
   unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
                               the dead last; later passes: the migrants, into rec_out) */
   unsigned* tile_count;    /* ntiles + 2: histogram of the counting sort (zero between uses) */
@@ -251,8 +261,9 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
                                  const int* abort_flag = nullptr,
                                  const unsigned* first_inactive = nullptr);
 const unsigned* tiled_first_inactive(const TiledArgs& t);
-/* slot_of_id from the ids of the records (after steps that kept id_out instead) */
-hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream);
+/* slot_of_id from the ids in the records (after steps that did not keep it) */
+hipError_t launch_invert_ids(const ParticleRec* rec, unsigned* slot_of_id, int n,
+                             hipStream_t stream);
 /* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
  * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
  * behind the first_slot records, holes closed at the end of the step (t.rec_out ->

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, Til
 #pragma unroll 4
   for (int k = 0; k < kSortItems; ++k) {
     const long long i = base + (long long)k * kSortBlock + threadIdx.x;
-    if (i < a.nparticles) {
+    if (i < t.sort_end) {
       const unsigned b = sort_bucket(t, info[i]);
       if (b != kNoBucket) {
         atomicAdd(in_lds ? &s_bins[b] : &t.tile_count[b], 1u);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
 #pragma unroll
   for (int k = 0; k < kSortItems; ++k) {
     const long long i = base + (long long)k * kSortBlock + threadIdx.x;
-    bucket[k] = (i < a.nparticles) ? sort_bucket(t, info[i]) : kNoBucket;
+    bucket[k] = (i < t.sort_end) ? sort_bucket(t, info[i]) : kNoBucket;
   }
   if (!in_lds) {
 #pragma unroll
@@ -286,15 +286,18 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
   }
 }
 
-/* pass 0: the records that sit the step out (the dead) are carried over behind the
- * live ones, which the stream kernel writes in tile order */
+/* pass 0: the records that sit the step out (the dead the sort found) are carried over
+ * behind the live ones, which the stream kernel writes in tile order; and the ones carried
+ * over a step ago are copied across to this buffer, where they stay (TiledArgs: graveyard) */
 __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, TiledArgs t) {
   if (a.abort_flag && *a.abort_flag) {
     return; /* (an abandoned attempt leaves slot_of_id as the last finished step made it) */
   }
   const unsigned first_inactive = t.tile_offset[t.ntiles];
-  const unsigned j = first_inactive + blockIdx.x * kSortBlock + threadIdx.x;
-  if (j < (unsigned)a.nparticles) {
+  const unsigned u = blockIdx.x * kSortBlock + threadIdx.x;
+  const unsigned ncarried = (unsigned)t.sort_end - first_inactive;
+  if (u < ncarried) {
+    const unsigned j = first_inactive + u;
     const unsigned src = t.order[j];
     const ParticleRec r = t.rec_in[src];
     t.rec_out[j] = r;
@@ -303,8 +306,12 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
       t.id_out[j] = t.id_in[src];
     } else if (t.slots_by_id) {
       t.slot_of_id[r.id] = j;
-    } else {
-      t.id_out[j] = r.id;
+    }
+  } else {
+    const unsigned m = (unsigned)t.sort_end + (u - ncarried);
+    if (m < (unsigned)t.mirror_end) {
+      t.rec_out[m] = t.rec_in[m]; /* same slot: slot_of_id stays */
+      t.info_out[m] = t.info_in[m];
     }
   }
 }
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
   __shared__ unsigned s_base;
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
   const int wave = threadIdx.x >> 6;
-  const bool susp = i < a.nparticles && summary_state(info[i]) == kRecCollide;
+  const bool susp = i < t.sort_end && summary_state(info[i]) == kRecCollide;
   const unsigned long long m = __ballot(susp);
   if ((threadIdx.x & 63) == 0) {
     s_count[wave] = (unsigned)__popcll(m);
@@ -376,11 +383,15 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
  * id instead costs one scattered 4-B write per particle (slot_of_id, by the kernel that
  * places the record: pass 0 of the stream kernel, copy_inactive, the import), one
  * random 80-B record read, and eleven fully coalesced stores. */
-__global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const unsigned* ids,
+__global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const ParticleRec* rec,
                                                                 unsigned* slot_of_id, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  if (i < n && ids[i] < (unsigned)n) {
-    slot_of_id[ids[i]] = (unsigned)i;
+  if (i < n) {
+    const unsigned id = rec[i].id; /* (a 64-B sector for 4 bytes: only where somebody asks
+                                      for the arrays after steps in lazy mode) */
+    if (id < (unsigned)n) {
+      slot_of_id[id] = (unsigned)i;
+    }
   }
 }
 
@@ -673,9 +684,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             if (t.pass == 0) {
               /* who lives in the slot / where the particle lives: what the write-back (or a
                * decomposed store's compaction) goes by, without reading 80-B records */
-              if (kDomain || !t.slots_by_id) {
+              if (kDomain) {
                 t.id_out[pid] = h.id;
-              } else {
+              } else if (t.slots_by_id) {
                 t.slot_of_id[h.id] = (unsigned)pid;
               }
             }
@@ -1128,10 +1139,11 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
 
 const unsigned* tiled_first_inactive(const TiledArgs& t) { return &t.ctrl[kCtrlFirstInactive]; }
 
-hipError_t launch_invert_ids(const unsigned* ids, unsigned* slot_of_id, int n, hipStream_t stream) {
+hipError_t launch_invert_ids(const ParticleRec* rec, unsigned* slot_of_id, int n,
+                             hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(invert_ids_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
-                       0, stream, ids, slot_of_id, n);
+                       0, stream, rec, slot_of_id, n);
   }
   return hipGetLastError();
 }
@@ -1141,8 +1153,9 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
                                       size_t lds, hipStream_t stream, hipEvent_t after_sort) {
   t.pass = pass;
   t.allow_migrate = (pass + 1 < kMaxStreamPasses) ? 1 : 0;
+  /* (the graveyard beyond sort_end takes no part; a grid of one block when nothing does) */
   const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
-  const int grid_seg = (a.nparticles + kSortSegment - 1) / kSortSegment;
+  const int grid_seg = t.sort_end > 0 ? (t.sort_end + kSortSegment - 1) / kSortSegment : 1;
   const int nbins = t.ntiles + 1;
   const size_t lds_bins = (nbins <= kSortLdsBins) ? sizeof(unsigned) * (size_t)nbins : 0;
   hipLaunchKernelGGL(tile_count_kernel, dim3(grid_seg), dim3(kSortBlock), lds_bins, stream, a, t);
@@ -1193,7 +1206,11 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     if (after_collect) (void)hipEventRecord(after_collect, stream);
     return hipSuccess;
   }
-  const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
+  if (a.decomposed || t.sort_end > a.nparticles || t.mirror_end < t.sort_end) {
+    t.sort_end = a.nparticles; /* (no graveyard: slots come and go within a step) */
+    t.mirror_end = a.nparticles;
+  }
+  const int grid_n = t.sort_end > 0 ? (t.sort_end + kSortBlock - 1) / kSortBlock : 1;
   int dev = 0;
   int cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {

@@ -228,6 +228,41 @@ def test_write_back_mode_can_change_between_steps(iface, make_problem, cs):
         sim.close()
 
 
+@pytest.mark.parametrize("lazy", [False, True])
+def test_the_dead_keep_their_slots_and_cost_nothing(iface, make_problem, cs, lazy):
+    """A particle that is dead when a step begins is carried over behind the live ones once,
+    copied across to the other record buffer once, and from then on takes no part in the
+    sort (the graveyard).  scatter: most particles die within the first steps, so later
+    steps run with (almost) nothing but graveyard -- down to an empty sort -- and the
+    arrays still equal variant 0's after every step; a re-injection starts over."""
+    prob = make_problem("scatter", nx=64, nparticles=20000, iterations=6)
+    ref = iface.Simulation(prob, *cs, variant=0)
+    sim = iface.Simulation(prob, *cs, variant=2)
+    iface.set_lazy_export(lazy)
+    try:
+        for round_ in range(2):
+            ref.inject()
+            sim.inject()
+            alive = []
+            for tt in range(1, 7):
+                r0 = ref.step(tt)
+                r2 = sim.step(tt)
+                assert (r0.nprocessed, r0.facets, r0.collisions) == (r2.nprocessed, r2.facets,
+                                                                     r2.collisions), (round_, tt)
+                alive.append(r2.nprocessed)
+                if tt in (1, 3, 4, 6):
+                    a, b = ref.particle_arrays(), sim.particle_arrays()
+                    for f in a:
+                        assert np.array_equal(a[f], b[f]), (round_, tt, f)
+            assert alive[0] == 20000 and alive[-1] < alive[0] // 10, alive
+        assert np.linalg.norm(ref.tally_host() - sim.tally_host()) <= 1e-13 * np.linalg.norm(
+            ref.tally_host())
+    finally:
+        iface.set_lazy_export(False)
+        ref.close()
+        sim.close()
+
+
 def test_two_live_stores_under_lazy_export(iface, make_problem, cs):
     """The record workspace is shared: stepping a second, larger store must first
     write the first store's pending state back (round-1 advisor finding)."""
