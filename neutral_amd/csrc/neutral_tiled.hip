@@ -304,7 +304,9 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
     t.info_out[j] = t.info_in[src];
     if (a.decomposed) {
       t.id_out[j] = t.id_in[src];
-    } else if (t.slots_by_id) {
+    } else {
+      /* (in lazy mode too: this is the last time the record moves, and a later eager step
+       * writes slot_of_id only for what it places itself) */
       t.slot_of_id[r.id] = j;
     }
   } else {

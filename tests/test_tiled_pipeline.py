@@ -203,64 +203,80 @@ def test_arrays_are_current_through_deaths_and_table_changes(iface, make_problem
     sim.close()
 
 
-def test_write_back_mode_can_change_between_steps(iface, make_problem, cs):
-    """Eager steps note where each particle's record is (slot_of_id), lazy steps note who
-    is in each slot (id_out, inverted when somebody asks for the arrays): switching
-    between them, and asking in between, always gives the arrays of variant 0."""
-    prob = make_problem("csp", nx=100, nparticles=40000, iterations=5, dt=1.0e-6)
-    ref = iface.Simulation(prob, *cs, variant=0)
-    sim = iface.Simulation(prob, *cs, variant=2)
-    ref.inject()
-    sim.inject()
+def _run_alone(iface, prob, cs, variant, schedule, rounds=1):
+    """One simulation stepped on its own (another store stepped in between would write
+    this one's pending records back -- the record workspace is shared -- and hide what the
+    schedule is there to expose).  schedule: (timestep, lazy or None, look) per step;
+    returns the arrays at the steps that look, the per-step counters and the tally."""
+    sim = iface.Simulation(prob, *cs, variant=variant)
+    looks, counters = [], []
     try:
-        for tt, lazy, look in ((1, True, False), (2, False, True), (3, True, True),
-                               (4, True, False), (5, False, True)):
-            iface.set_lazy_export(lazy)
-            ref.step(tt)
-            sim.step(tt)
-            if look:
-                a, b = ref.particle_arrays(), sim.particle_arrays()
-                for f in a:
-                    assert np.array_equal(a[f], b[f]), (tt, f)
+        for _ in range(rounds):
+            sim.inject()
+            for tt, lazy, look in schedule:
+                if lazy is not None:
+                    iface.set_lazy_export(lazy if variant == 2 else False)
+                r = sim.step(tt)
+                counters.append((r.nprocessed, r.facets, r.collisions))
+                if look:
+                    looks.append((tt, sim.particle_arrays()))
+        tally = sim.tally_host()
     finally:
         iface.set_lazy_export(False)
-        ref.close()
         sim.close()
+    return looks, counters, tally
 
 
+def _same_looks(want, got):
+    assert want[1] == got[1]
+    for (tt, a), (_, b) in zip(want[0], got[0]):
+        for f in a:
+            assert np.array_equal(a[f], b[f]), (tt, f)
+    assert np.linalg.norm(want[2] - got[2]) <= 1e-13 * np.linalg.norm(want[2])
+
+
+@pytest.mark.parametrize("deck,nx,n,dt", [("csp", 100, 40000, 1.0e-6),
+                                          ("split", 64, 30000, 2.0e-8)])  # deaths every step
+def test_write_back_mode_can_change_between_steps(iface, make_problem, cs, deck, nx, n, dt):
+    """Eager steps note where each particle's record is (slot_of_id); lazy steps do not, and
+    whoever asks for the arrays then reads the ids out of the records first.  The dead are
+    the exception: their record moves for the last time when it is carried over, in either
+    mode.  Switching between the modes, and asking in between or not, always gives the
+    arrays of variant 0."""
+    prob = make_problem(deck, nx=nx, nparticles=n, iterations=6, dt=dt)
+    schedule = ((1, True, False), (2, False, True), (3, True, True), (4, True, False),
+                (5, False, True), (6, True, True))
+    want = _run_alone(iface, prob, cs, 0, schedule)
+    got = _run_alone(iface, prob, cs, 2, schedule)
+    _same_looks(want, got)
+    if deck == "split":
+        # particles died during the lazy steps 3 and 4: their records were carried over for
+        # good by lazy steps, and the eager step 5 had to find them
+        alive = [c[0] for c in want[1]]
+        assert alive[3] < alive[2] and alive[4] < alive[3], alive
+
+
+@pytest.mark.parametrize("deck,dt", [("scatter", None), ("split", 2.0e-8)])
 @pytest.mark.parametrize("lazy", [False, True])
-def test_the_dead_keep_their_slots_and_cost_nothing(iface, make_problem, cs, lazy):
+def test_the_dead_keep_their_slots_and_cost_nothing(iface, make_problem, cs, lazy, deck, dt):
     """A particle that is dead when a step begins is carried over behind the live ones once,
     copied across to the other record buffer once, and from then on takes no part in the
-    sort (the graveyard).  scatter: most particles die within the first steps, so later
-    steps run with (almost) nothing but graveyard -- down to an empty sort -- and the
-    arrays still equal variant 0's after every step; a re-injection starts over."""
-    prob = make_problem("scatter", nx=64, nparticles=20000, iterations=6)
-    ref = iface.Simulation(prob, *cs, variant=0)
-    sim = iface.Simulation(prob, *cs, variant=2)
-    iface.set_lazy_export(lazy)
-    try:
-        for round_ in range(2):
-            ref.inject()
-            sim.inject()
-            alive = []
-            for tt in range(1, 7):
-                r0 = ref.step(tt)
-                r2 = sim.step(tt)
-                assert (r0.nprocessed, r0.facets, r0.collisions) == (r2.nprocessed, r2.facets,
-                                                                     r2.collisions), (round_, tt)
-                alive.append(r2.nprocessed)
-                if tt in (1, 3, 4, 6):
-                    a, b = ref.particle_arrays(), sim.particle_arrays()
-                    for f in a:
-                        assert np.array_equal(a[f], b[f]), (round_, tt, f)
-            assert alive[0] == 20000 and alive[-1] < alive[0] // 10, alive
-        assert np.linalg.norm(ref.tally_host() - sim.tally_host()) <= 1e-13 * np.linalg.norm(
-            ref.tally_host())
-    finally:
-        iface.set_lazy_export(False)
-        ref.close()
-        sim.close()
+    sort (the graveyard).  scatter: every particle dies in the first step, so later steps
+    run with nothing but graveyard and an empty sort; split at a short dt: a few thousand
+    die in every step.  The arrays still equal variant 0's at every look; a re-injection
+    starts over."""
+    kw = dict(nx=64, nparticles=20000, iterations=6)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    schedule = tuple((tt, lazy, tt in (1, 3, 4, 6)) for tt in range(1, 7))
+    want = _run_alone(iface, prob, cs, 0, schedule, rounds=2)
+    got = _run_alone(iface, prob, cs, 2, schedule, rounds=2)
+    _same_looks(want, got)
+    alive = [c[0] for c in want[1]][:6]
+    assert alive[0] == 20000 and alive[-1] < alive[0] // 2, alive
+    if deck == "split":
+        assert all(x > y for x, y in zip(alive, alive[1:])), alive
 
 
 def test_two_live_stores_under_lazy_export(iface, make_problem, cs):
