@@ -144,6 +144,31 @@ __global__ __launch_bounds__(256) void alignbit_kernel(unsigned* out, unsigned s
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3;              \
   }
 
+// byte-granular alternatives to v_alignbit_b32 for Threefry's rotations by 16 and 24
+U32_KERNEL(perm32_kernel,
+  asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "s"(0x01000706u));
+  asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a1) : "v"(a2), "s"(0x01000706u));
+  asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a2) : "v"(a3), "s"(0x01000706u));
+  asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a3) : "v"(a0), "s"(0x01000706u));)
+
+U32_KERNEL(alignbyte32_kernel,
+  asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(a0) : "v"(a1));
+  asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(a1) : "v"(a2));
+  asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(a2) : "v"(a3));
+  asm volatile("v_alignbyte_b32 %0, %0, %1, 2" : "+v"(a3) : "v"(a0));)
+
+U32_KERNEL(lshlor32_kernel,
+  asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(a0) : "v"(a1));
+  asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(a1) : "v"(a2));
+  asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(a2) : "v"(a3));
+  asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(a3) : "v"(a0));)
+
+U32_KERNEL(lshrrev32_kernel,
+  asm volatile("v_lshrrev_b32 %0, 7, %1" : "+v"(a0) : "v"(a1));
+  asm volatile("v_lshrrev_b32 %0, 7, %1" : "+v"(a1) : "v"(a2));
+  asm volatile("v_lshrrev_b32 %0, 7, %1" : "+v"(a2) : "v"(a3));
+  asm volatile("v_lshrrev_b32 %0, 7, %1" : "+v"(a3) : "v"(a0));)
+
 U32_KERNEL(xor32_kernel,
   asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a0) : "v"(a1));
   asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a1) : "v"(a2));
@@ -219,6 +244,12 @@ int main() {
     if (run("add u64", add64i_kernel, (uint64_t*)buf, (uint64_t)3, kIters * 32.0, blocks, "op")) return 1;
     if (run("alignbit b32", alignbit_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
     if (run("v_xor_b32", xor32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    if (per_cu == 12) {
+      if (run("v_perm_b32", perm32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_alignbyte_b32", alignbyte32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_lshl_or_b32", lshlor32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+      if (run("v_lshrrev_b32", lshrrev32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
+    }
     if (run("v_add_co_u32", addco32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
     if (run("v_add_u32", addu32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
     if (run("v_cndmask_b32", cndmask32_kernel, (unsigned*)buf, 3u, kIters * 32.0, blocks, "op")) return 1;
