@@ -202,12 +202,8 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
  * give the same correctly rounded bits (tested against numpy on the device,
  * tests/test_hip_parity.py); zero is answered directly and everything else goes
  * to the ordinary sqrt. */
-__device__ __forceinline__ double sqrt_plain_range(double x) {
-  const unsigned hi = (unsigned)__double2hiint(x);
-  if (__builtin_expect(!((hi - (523u << 20)) < (1000u << 20)), 0)) { /* also negative, NaN, inf, 0 */
-    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
-    return sqrt(x);
-  }
+/* the ten operations alone: for arguments KNOWN to lie in [2^-500, 2^500] */
+__device__ __forceinline__ double sqrt_known_plain(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   const double g0 = x * y;
   const double h0 = 0.5 * y;
@@ -218,6 +214,46 @@ __device__ __forceinline__ double sqrt_plain_range(double x) {
   const double g2 = __builtin_fma(d0, h1, g1);
   const double d1 = __builtin_fma(-g2, g2, x);
   return __builtin_fma(d1, h1, g2);
+}
+
+__device__ __forceinline__ double sqrt_plain_range(double x) {
+  const unsigned hi = (unsigned)__double2hiint(x);
+  if (__builtin_expect(!((hi - (523u << 20)) < (1000u << 20)), 0)) { /* also negative, NaN, inf, 0 */
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    return sqrt(x);
+  }
+  return sqrt_known_plain(x);
+}
+
+/* Roots whose argument cannot leave the plain range in any run the reference defines.  A
+ * particle's energy lies inside the cross-section tables' keys (1e-2 ... 1e8 eV in the
+ * shipped tables; outside them omp3/neutral.c:498-517 reads out of bounds or never
+ * returns), so
+ *   - the speed's argument 2 E eV / m (omp3/neutral.c:116,298) is E * 1.9e8,
+ *   - the energy ratios E'/E and E/E' of a scatter (:264-265) lie in [(A-1)^2/(A+1)^2, its
+ *     inverse] = [0.96, 1.04] whatever E is,
+ * and the range test -- a compare, an exec-mask save and restore and a branch per root,
+ * in the collision stage where scalar work and branches are what the waves wait on -- can
+ * never fire.  NEUTRAL_CHECKED_RANGES=1 brings it back (same bits; A/B in DESIGN.md). */
+/* sqrt(1 - cos^2) of a scattering angle (omp3/neutral.c:266): the argument is +0 -- a
+ * head-on cosine of exactly 1 -- or at least an ulp of 1 (2^-53), never in between and
+ * never -0; zero is answered by a select instead of a branch.  (A cosine that rounding
+ * pushed beyond 1 gives a negative argument and NaN here as in the reference.) */
+__device__ __forceinline__ double sqrt_of_sine_squared(double x) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return sqrt_plain_range(x);
+#else
+  const double r = sqrt_known_plain(x);
+  return (x == 0.0) ? 0.0 : r;
+#endif
+}
+
+__device__ __forceinline__ double sqrt_of_physical(double x) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return sqrt_plain_range(x);
+#else
+  return sqrt_known_plain(x);
+#endif
 }
 
 /* ---- log of a sample (omp3/neutral.c:131,295: mfp = -log(rn)/Sigma_s) -----------
@@ -235,22 +271,7 @@ __device__ __forceinline__ double sqrt_plain_range(double x) {
  * depended on its last bit (section 3 of DESIGN.md).  Samples lie in [2^-65, 1];
  * zero, negative, subnormal, infinite and NaN arguments get log()'s answers from a
  * rare branch. */
-__device__ __forceinline__ double log_of_sample(double x) {
-  int k_scaled = 0;
-  if (__builtin_expect(!((x >= 2.2250738585072014e-308) & (x <= 1.7976931348623157e308)), 0)) {
-    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
-    if (x == 0.0) {
-      return -__builtin_huge_val();
-    }
-    if (!(x > 0.0)) {
-      return __builtin_nan(""); /* negative or NaN */
-    }
-    if (x > 1.7976931348623157e308) {
-      return x; /* +inf */
-    }
-    x *= 18014398509481984.0; /* subnormal: scaled by 2^54 */
-    k_scaled = -54;
-  }
+__device__ __forceinline__ double log_core(double x, int k_scaled) {
   double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
   int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
   const bool low = (m < 0.70710678118654752440);
@@ -275,6 +296,36 @@ __device__ __forceinline__ double log_of_sample(double x) {
   constexpr double ln2_hi = 0.6931471803691238;     /* 0x3fe62e42fee00000: 32 significant bits */
   constexpr double ln2_lo = 1.9082149292705877e-10; /* ln 2 - ln2_hi */
   return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + dk * ln2_lo)) - f);
+}
+
+/* any argument: zero, negative, subnormal, infinite and NaN get log()'s answers */
+__device__ __forceinline__ double log_of_sample(double x) {
+  int k_scaled = 0;
+  if (__builtin_expect(!((x >= 2.2250738585072014e-308) & (x <= 1.7976931348623157e308)), 0)) {
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    if (x == 0.0) {
+      return -__builtin_huge_val();
+    }
+    if (!(x > 0.0)) {
+      return __builtin_nan(""); /* negative or NaN */
+    }
+    if (x > 1.7976931348623157e308) {
+      return x; /* +inf */
+    }
+    x *= 18014398509481984.0; /* subnormal: scaled by 2^54 */
+    k_scaled = -54;
+  }
+  return log_core(x, k_scaled);
+}
+
+/* a sample as generate_random_numbers makes it: u64 * 2^-64 + 2^-65, in [2^-65, 1] -- the
+ * special cases above cannot occur (same switch as sqrt_of_physical) */
+__device__ __forceinline__ double log_of_drawn_sample(double x) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return log_of_sample(x);
+#else
+  return log_core(x, 0);
+#endif
 }
 
 /* ---- quotients by a denominator that many numerators share --------------------
@@ -325,6 +376,17 @@ __device__ __forceinline__ double quotient_by_constant(double a, double b, doubl
   asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
   return a / b;
 }
+/* the same for a numerator that cannot leave the plain range in a run the reference
+ * defines (see sqrt_of_physical): an energy of 1e-2 ... 1e8 eV times 2 eV_TO_J (3.2e-19),
+ * or times A^2 + 2 A mu + 1 (9 801 ... 10 201) -- no range test, no branch */
+template <typename Tag>
+__device__ __forceinline__ double quotient_of_physical_by_constant(double a, double b, double y) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return quotient_by_constant<Tag>(a, b, y);
+#else
+  return quotient_by_reciprocal(a, b, y);
+#endif
+}
 struct ByParticleMass {};
 struct ByMassNoPlusOneSquared {};
 constexpr double kMassNoPlusOneSquared = (kMassNo + 1.0) * (kMassNo + 1.0);
@@ -349,8 +411,8 @@ __device__ __forceinline__ void calc_distance_to_facet(
 
 __device__ __forceinline__ double speed_of(double energy) {
   /* omp3/neutral.c:117,297 */
-  return sqrt_plain_range(quotient_by_constant<ByParticleMass>(2.0 * energy * kEvToJ, kParticleMass,
-                                                                1.0 / kParticleMass));
+  return sqrt_of_physical(quotient_of_physical_by_constant<ByParticleMass>(
+      2.0 * energy * kEvToJ, kParticleMass, 1.0 / kParticleMass));
 }
 
 }  // namespace neutral

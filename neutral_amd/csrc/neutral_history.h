@@ -320,11 +320,21 @@ __device__ __forceinline__ void macroscopic_from_density(History& h) {
  * data: x + x is exact and the quotient is exactly one half unless x is zero,
  * infinite or NaN, or the sum overflows -- those go through the division. */
 __device__ __forceinline__ double half_or_quotient(double x, double sum) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
   if (__builtin_expect(sum != 0.0 && fabs(sum) < __builtin_huge_val(), 1)) {
     return 0.5;
   }
   asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
   return x / sum;
+#else
+  /* One half, without the test (neutral_device.h: sqrt_of_physical has the reasoning for
+   * this switch).  A cross section that is zero, infinite or NaN cannot reach the two
+   * callers in a run with a meaningful result: a collision needs a finite distance to it,
+   * i.e. a finite non-zero macroscopic cross section (the comparisons of
+   * omp3/neutral.c:160-163 are false for NaN), and a zero microscopic one makes the
+   * reference's own heating 0/0 and its tally NaN. */
+  return 0.5;
+#endif
 }
 
 __device__ __forceinline__ void refresh_speed_reciprocal(History& h) {
@@ -495,7 +505,7 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   h.dt_to_census = a.dt;
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  h.mfp_to_collision = -log_of_sample(rn0) / h.macro_s;
+  h.mfp_to_collision = -log_of_drawn_sample(rn0) / h.macro_s;
   refresh_direction(h);
   refresh_deposition_terms<kSameTables>(h);
 }
@@ -609,36 +619,34 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
 
   const bool absorbed = (rc0 < p_absorb);
-  if (absorbed) {
-    /* absorption: the weight drops; below 1 eV the history ends here */
-    h.weight *= (1.0 - p_absorb);
-    if (h.energy < kMinEnergyOfInterest) {
-      h.dead = 1;
-      tally(a, h.cellx, h.celly, h.energy_deposition);
-      h.energy_deposition = 0.0;
-      if (Tally::kFlux) {
-        tally.flux(a, h.cellx, h.celly, h.track_length);
-        h.track_length = 0.0;
-      }
-      return true;
+  /* absorption: the weight drops; below 1 eV the history ends here.  The short pieces
+   * are selects: a divergent region costs the collision stage more in exec-mask
+   * bookkeeping and a branch than the few vector instructions it would skip. */
+  const double absorbed_weight = h.weight * (1.0 - p_absorb);
+  h.weight = absorbed ? absorbed_weight : h.weight;
+  if (__builtin_expect(absorbed & (h.energy < kMinEnergyOfInterest), 0)) {
+    h.dead = 1;
+    tally(a, h.cellx, h.celly, h.energy_deposition);
+    h.energy_deposition = 0.0;
+    if (Tally::kFlux) {
+      tally.flux(a, h.cellx, h.celly, h.track_length);
+      h.track_length = 0.0;
     }
+    return true;
   }
   /* The energy after the collision is known before the scattering angle is: the
    * table search for it (:281-286) starts here, and its first probe is in flight
    * while the scattered lanes work out their direction (:254-272). */
-  double e_new = h.energy;
-  if (!absorbed) {
-    /* elastic scatter off a nucleus of mass number A */
-    const double mu_cm = 1.0 - 2.0 * rc1;
-    e_new = quotient_by_constant<ByMassNoPlusOneSquared>(
-        h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared,
-        1.0 / kMassNoPlusOneSquared);
-  }
+  const double mu_cm = 1.0 - 2.0 * rc1;
+  const double e_scattered = quotient_of_physical_by_constant<ByMassNoPlusOneSquared>(
+      h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared,
+      1.0 / kMassNoPlusOneSquared);
+  const double e_new = absorbed ? h.energy : e_scattered;
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {
-    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt_plain_range(e_new / h.energy) -
-                                    (kMassNo - 1.0) * sqrt_plain_range(h.energy / e_new));
-    const double sin_theta = sqrt_plain_range(1.0 - cos_theta * cos_theta);
+    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt_of_physical(e_new / h.energy) -
+                                    (kMassNo - 1.0) * sqrt_of_physical(h.energy / e_new));
+    const double sin_theta = sqrt_of_sine_squared(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
     h.omega_x = omega_x_new;
@@ -650,7 +658,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
    * and its logarithm are worked out while the search is still in flight */
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  const double minus_log_rn0 = -log_of_sample(rn0);
+  const double minus_log_rn0 = -log_of_drawn_sample(rn0);
 
   lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
   macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */

@@ -138,6 +138,8 @@ struct SolveArgs {
   /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
    * eleven more array pointers (the collision stage): read where a history ends */
   const ParticleView* export_view;
+  int occupancy_rows;         /* collision stage: workgroups per CU resident together, among
+                                 which the kernel picks how many work (0: all) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
                                  since before it are left alone by the write-back pass */
   /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,

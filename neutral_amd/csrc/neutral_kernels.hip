@@ -46,7 +46,7 @@ constexpr int kBlock = 256;
 #define NEUTRAL_K2_WAVES 3
 #endif
 #ifndef NEUTRAL_K2_QUEUE_WAVES
-#define NEUTRAL_K2_QUEUE_WAVES 3
+#define NEUTRAL_K2_QUEUE_WAVES 4
 #endif
 
 /* ---- K0: injection --------------------------------------------------------- */
@@ -330,7 +330,8 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * spill); kQueue = true: the collision stage of the tiled pipeline, histories
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
 template <bool kSameTables, bool kQueue, bool kFlux>
-__global__ __launch_bounds__(kBlock, kQueue ? NEUTRAL_K2_QUEUE_WAVES : NEUTRAL_K2_WAVES)
+__global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux) ? NEUTRAL_K2_QUEUE_WAVES : 3)
+                                             : NEUTRAL_K2_WAVES)
 void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
   unsigned ncollisions = 0;
@@ -340,26 +341,30 @@ void history_regroup_kernel(SolveArgs a) {
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
   }
-  /* Collision stage, launched three workgroups per CU (a.blocks_per_cu == -1): how many
-   * of them work is decided HERE, from the queue length the host has not seen yet.  A
-   * collider is a serial chain of ~10^3 collisions; with few of them the stage lasts
-   * one chain, and a chain runs faster the fewer waves share its SIMD (csp, per chain:
-   * 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with two: profiles/r01f), so a
-   * queue that fits one (two) workgroup(s) per CU keeps exactly that many.  Workgroups
-   * b, b + #CUs, b + 2 #CUs share a CU under every dispatch order tried (and nothing
-   * breaks if they do not: this is an occupancy hint), and #CUs = 1 mod 3, so "b mod 3 <
-   * wanted" leaves `wanted` of them on each CU. */
+  /* Collision stage, launched as many workgroups per CU as stay resident (a.occupancy_rows,
+   * one wave of each per SIMD): how many of them work is decided HERE, from the queue
+   * length the host has not seen yet.  A collider is a serial chain of ~10^3 collisions;
+   * with few of them the stage lasts one chain, and a chain runs faster the fewer waves
+   * share its SIMD (csp, per chain: 2.4 ms alone, 3.6 ms with one neighbour, 4.9 ms with
+   * two: profiles/r01f), so a queue that fits one (two, ...) workgroup(s) per CU keeps
+   * exactly that many.  Workgroups b, b + #CUs, b + 2 #CUs, ... share a CU under every
+   * dispatch order tried (and nothing breaks if they do not: this is an occupancy hint),
+   * so the first `wanted` rows of #CUs workgroups stay. */
   int block_index = (int)blockIdx.x;
   int block_count = (int)gridDim.x;
-  if (kQueue && a.blocks_per_cu == -1) {
+  if (kQueue && a.occupancy_rows > 0) {
     const unsigned queued = *a.queue_len;
-    const unsigned row_lanes = (gridDim.x / 3u) * (unsigned)kBlock;
-    const int wanted = (queued <= row_lanes) ? 1 : (queued <= 2u * row_lanes) ? 2 : 3;
-    if ((int)(blockIdx.x % 3u) >= wanted) {
+    const unsigned rows = (unsigned)a.occupancy_rows;
+    const unsigned per_row = gridDim.x / rows;
+    const unsigned row_lanes = per_row * (unsigned)kBlock;
+    unsigned wanted = (queued + row_lanes - 1u) / row_lanes;
+    wanted = (wanted < 1u) ? 1u : ((wanted > rows) ? rows : wanted);
+    const unsigned row = blockIdx.x / per_row;
+    if (row >= wanted) {
       return;
     }
-    block_index = (int)(blockIdx.x / 3u) * wanted + (int)(blockIdx.x % 3u);
-    block_count = (int)(gridDim.x / 3u) * wanted;
+    block_index = (int)((blockIdx.x % per_row) * wanted + row);
+    block_count = (int)(per_row * wanted);
   }
   /* stage the bucketed cs index(es) in LDS: nbuckets+1 u16 entries each */
   extern __shared__ unsigned short lds_index[];
@@ -952,19 +957,20 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
       int grid = resident_blocks(kernel, lds);
+      k.occupancy_rows = 0;
       if (a.blocks_per_cu == -1) {
-        /* the kernel picks its own occupancy, which needs exactly three workgroups per
-         * CU in flight and #CUs = 1 mod 3; otherwise everybody works */
+        /* the kernel picks its own occupancy among the rows of #CUs workgroups that are
+         * resident together; otherwise everybody works */
         int cus = 256;
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) {
           (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         }
-        const bool fits = (grid == 3 * cus) && (cus % 3 == 1) && (want_blocks >= grid) &&
+        const int rows = grid / cus;
+        const bool fits = (rows >= 2) && (grid == rows * cus) && (want_blocks >= grid) &&
                           !(a.max_blocks > 0 && a.max_blocks < grid);
-        if (!fits) {
-          k.blocks_per_cu = 0;
-        }
+        k.occupancy_rows = fits ? rows : 0;
+        k.blocks_per_cu = 0;
       }
       if (a.blocks_per_cu > 0) {
         /* the caller knows how little work there is: fewer resident waves per
