@@ -181,6 +181,8 @@ __device__ __forceinline__ int cs_bracket_indexed(const double* __restrict__ key
   return lo;
 }
 
+__device__ __forceinline__ double quotient_of_physical(double a, double b); /* below */
+
 __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys,
                                                  const double* __restrict__ values,
                                                  int ind, double energy) {
@@ -190,7 +192,7 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
   const double k1 = k[1];
   const double v0 = v[0];
   const double v1 = v[1];
-  return v0 + ((energy - k0) / (k1 - k0)) * (v1 - v0);
+  return v0 + quotient_of_physical(energy - k0, k1 - k0) * (v1 - v0);
 }
 
 /* ---- square root without the wrapping ---------------------------------------------
@@ -360,6 +362,22 @@ __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, dou
   const double q0 = a * r;
   const double rem = __builtin_fma(-b, q0, a);
   return __builtin_fma(rem, r, q0);
+}
+
+/* a / b where neither operand nor the quotient can leave the plain range in a run the
+ * reference defines, and a may be +0 (not -0): the interpolation weight (E - k0)/(k1 - k0)
+ * of a table lookup (omp3/neutral.c:514: keys are positive and increasing, E >= k0, a
+ * difference of doubles of magnitude 1e-2 ... 1e8 is zero or at least 1e-18), the mean free
+ * path 1/(Sigma_s + Sigma_a) (:135) and the flight time d/speed (:297).  Eight operations
+ * instead of the wrapped division's thirteen, same bits (the refined reciprocal and the
+ * three operations of quotient_by_reciprocal: tested against the compiler's division,
+ * tests/test_hip_parity.py); NEUTRAL_CHECKED_RANGES=1 divides. */
+__device__ __forceinline__ double quotient_of_physical(double a, double b) {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return a / b;
+#else
+  return quotient_by_reciprocal(a, b, refined_reciprocal(b));
+#endif
 }
 
 /* a / b for a compile-time constant b: with y = RN(1/b) (rounded correctly by the

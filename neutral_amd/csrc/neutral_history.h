@@ -304,7 +304,7 @@ __device__ __forceinline__ void lookup_cs_finish(const SolveArgs& a, const CsSea
 __device__ __forceinline__ void macroscopic_from_micro(History& h) {
   h.macro_s = h.number_density * h.micro_s * kBarns;
   h.macro_a = h.number_density * h.micro_a * kBarns;
-  h.cell_mfp = 1.0 / (h.macro_s + h.macro_a);
+  h.cell_mfp = quotient_of_physical(1.0, h.macro_s + h.macro_a);
 }
 
 __device__ __forceinline__ void macroscopic_from_density(History& h) {
@@ -349,8 +349,8 @@ __device__ __forceinline__ void refresh_mfp_reciprocal(History& h) {
 
 /* omp3/neutral.c:435-436 */
 __device__ __forceinline__ void refresh_direction(History& h) {
-  h.u_x_inv = 1.0 / (h.omega_x * h.speed);
-  h.u_y_inv = 1.0 / (h.omega_y * h.speed);
+  h.u_x_inv = 1.0 / (h.omega_x * h.speed); /* (a cosine can be exactly zero: the wrapped */
+  h.u_y_inv = 1.0 / (h.omega_y * h.speed); /*  division; a select around the plain one: +-0) */
 }
 
 /* the energy- and table-dependent factors of calculate_energy_deposition
@@ -644,8 +644,9 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   const double e_new = absorbed ? h.energy : e_scattered;
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {
-    const double cos_theta = 0.5 * ((kMassNo + 1.0) * sqrt_of_physical(e_new / h.energy) -
-                                    (kMassNo - 1.0) * sqrt_of_physical(h.energy / e_new));
+    const double cos_theta =
+        0.5 * ((kMassNo + 1.0) * sqrt_of_physical(quotient_of_physical(e_new, h.energy)) -
+               (kMassNo - 1.0) * sqrt_of_physical(quotient_of_physical(h.energy, e_new)));
     const double sin_theta = sqrt_of_sine_squared(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
@@ -662,8 +663,8 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
 
   lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
   macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
-  h.mfp_to_collision = minus_log_rn0 / h.macro_s;
-  h.dt_to_census -= distance_to_collision / h.speed;
+  h.mfp_to_collision = minus_log_rn0 / h.macro_s; /* (-0.0 for a sample of exactly 1) */
+  h.dt_to_census -= quotient_of_physical(distance_to_collision, h.speed);
   h.speed = speed_of(h.energy);
   refresh_direction(h);
   refresh_deposition_terms<kSameTables>(h);
