@@ -339,12 +339,16 @@ __device__ __forceinline__ double half_or_quotient(double x, double sum) {
 
 __device__ __forceinline__ void refresh_speed_reciprocal(History& h) {
   h.r_speed = refined_reciprocal(h.speed);
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
   h.plain_div = (h.plain_div & ~1) | (in_plain_division_range(h.speed) ? 1 : 0);
+#endif
 }
 
 __device__ __forceinline__ void refresh_mfp_reciprocal(History& h) {
   h.r_cell_mfp = refined_reciprocal(h.cell_mfp);
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
   h.plain_div = (h.plain_div & ~2) | (in_plain_division_range(h.cell_mfp) ? 2 : 0);
+#endif
 }
 
 /* omp3/neutral.c:435-436 */
@@ -718,6 +722,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   const double distance_to_facet = h.distance;
   if (kCachedReciprocals) {
     /* both quotients of :311-312 through the kept reciprocals */
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
     if (__builtin_expect((h.plain_div == 3) & in_plain_division_range(distance_to_facet), 1)) {
       h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
       h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
@@ -726,9 +731,18 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
       h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
       h.dt_to_census -= (distance_to_facet / h.speed);
     }
+#else
+    /* No range test (neutral_device.h: sqrt_of_physical has the reasoning).  A distance to
+     * a facet is +0 (the particle sits on the edge it is heading for) or at least an ulp
+     * of a coordinate times a speed/speed ratio, i.e. > 1e-20, and at most the mesh; a
+     * speed is 1e3 ... 1e8 and a mean free path 1e-6 ... 1e29 (densities of 1e-30 ... 1e4:
+     * the reference's vacuum is 1e-30, because zero makes its own quotients 0/0). */
+    h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
+    h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
+#endif
   } else {
-    h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
-    h.dt_to_census -= (distance_to_facet / h.speed);
+    h.mfp_to_collision -= quotient_of_physical(distance_to_facet, h.cell_mfp);
+    h.dt_to_census -= quotient_of_physical(distance_to_facet, h.speed);
   }
   h.energy_deposition += deposit(h, distance_to_facet);
   tally(a, h.cellx, h.celly, h.energy_deposition);
@@ -771,7 +785,7 @@ __device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tal
   const double distance_to_census = h.distance;
   h.x += distance_to_census * h.omega_x;
   h.y += distance_to_census * h.omega_y;
-  h.mfp_to_collision -= (distance_to_census / h.cell_mfp);
+  h.mfp_to_collision -= quotient_of_physical(distance_to_census, h.cell_mfp);
   h.energy_deposition += deposit(h, distance_to_census);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   if (Tally::kFlux) {
