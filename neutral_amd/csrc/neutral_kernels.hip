@@ -45,6 +45,12 @@ constexpr int kBlock = 256;
 #ifndef NEUTRAL_K2_WAVES
 #define NEUTRAL_K2_WAVES 3
 #endif
+/* (experiment switch: NEUTRAL_NO_COLD_ARGS keeps every argument in registers) */
+#if defined(NEUTRAL_NO_COLD_ARGS)
+#define NEUTRAL_COLD_ARGS(a) (a)
+#else
+#define NEUTRAL_COLD_ARGS(a) (kQueue ? cold_args() : (a))
+#endif
 #ifndef NEUTRAL_K2_QUEUE_WAVES
 #define NEUTRAL_K2_QUEUE_WAVES 4
 #endif
@@ -304,6 +310,32 @@ constexpr int kPoolMaxShare = NEUTRAL_POOL_MAX_SHARE;
 constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is valid */
 
 
+/* The kernel's arguments, read again from the kernarg segment: for the cold paths of the
+ * collision stage (refill, hand-back, facet and census of a stray history, end of a time
+ * slice).  Used there instead of `a`, their pointers and mesh constants are scalar loads at
+ * the point of use instead of scalar registers held -- or, the scalar file being full,
+ * spilled to vector-register lanes and read back with v_readlane -- across the collision
+ * loop.  (The opaque asm keeps the loads from being hoisted back to the kernel's entry.) */
+__device__ __forceinline__ SolveArgs cold_args() {
+  static_assert(sizeof(SolveArgs) % 4 == 0, "SolveArgs is read back word by word");
+  union {
+    SolveArgs a;
+    unsigned w[sizeof(SolveArgs) / 4];
+  } u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) unsigned* KernargWords;
+  KernargWords p = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(SolveArgs) / 4; ++i) {
+    u.w[i] = p[i]; /* (scalar loads; the words nobody reads are never loaded) */
+  }
+#else
+  __builtin_memset(&u, 0, sizeof(u));
+#endif
+  return u.a;
+}
+
 /* final state of a history: into the SoA store, or into its record in queue mode */
 template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
@@ -500,17 +532,18 @@ void history_regroup_kernel(SolveArgs a) {
       const int n_take = (n_refill < ring_count) ? n_refill : ring_count;
       const int rank = lane_rank(m_refill);
       if (want == kWantRefill && rank < n_take) {
+        const SolveArgs c = NEUTRAL_COLD_ARGS(a);
         const unsigned e = *ring_slot(ring_head + rank);
         pid = (int)(e & ~kRequeued);
-        load_record(h, a, a.rec[pid]);
-        resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
+        load_record(h, c, c.rec[pid]);
+        resume<kSameTables>(h, c, ix); /* counted as processed by the suspender */
         if (e & kRequeued) {
-          const SuspendExtra x = a.susp[pid];
+          const SuspendExtra x = c.susp[pid];
           h.energy_deposition = x.energy_deposition;
           h.counter = x.counter;
           h.nevents = x.nevents;
           if (kFlux) {
-            h.track_length = a.susp_track[pid];
+            h.track_length = c.susp_track[pid];
           }
         }
         next_event(true);
@@ -545,9 +578,10 @@ void history_regroup_kernel(SolveArgs a) {
         if (kQueue) {
           /* a history the streaming kernel suspended: its record is the state */
           if (take) {
-            pid = (int)a.queue[mine];
-            load_record(h, a, a.rec[pid]);
-            resume<kSameTables>(h, a, ix); /* counted as processed by the suspender */
+            const SolveArgs c = NEUTRAL_COLD_ARGS(a);
+            pid = (int)c.queue[mine];
+            load_record(h, c, c.rec[pid]);
+            resume<kSameTables>(h, c, ix); /* counted as processed by the suspender */
           }
         } else if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
           pid = mine;
@@ -579,7 +613,7 @@ void history_regroup_kernel(SolveArgs a) {
             ncollisions++;
           }
           if (collide<kSameTables>(h, a, ix, tally)) {
-            put_back<kQueue>(h, a, pid);
+            put_back<kQueue>(h, NEUTRAL_COLD_ARGS(a), pid);
             want = kWantRefill;
           } else {
             next_event_after_collision();
@@ -609,14 +643,15 @@ void history_regroup_kernel(SolveArgs a) {
         const bool out = (want == kWantCollide);
         const unsigned long long m_out = __ballot(out);
         if (out) {
-          store_record(h, a, a.rec[pid], kRecCollide);
+          const SolveArgs c = NEUTRAL_COLD_ARGS(a);
+          store_record(h, c, c.rec[pid], kRecCollide);
           SuspendExtra x;
           x.energy_deposition = h.energy_deposition;
           x.counter = h.counter;
           x.nevents = h.nevents;
-          a.susp[pid] = x;
+          c.susp[pid] = x;
           if (kFlux) {
-            a.susp_track[pid] = h.track_length;
+            c.susp_track[pid] = h.track_length;
           }
           /* outstanding histories never exceed the share: the slot is free */
           int back = ring_head + ring_count;
@@ -635,15 +670,16 @@ void history_regroup_kernel(SolveArgs a) {
     } else {
       /* ---- STREAM pass: facet crossings, census, end of history ---- */
       if (want == kWantStream) {
+        const SolveArgs c = NEUTRAL_COLD_ARGS(a);
         if (h.ev == kEvFacet) {
           nfacets++;
-          cross_facet(h, a, tally);
-          if (kQueue && a.decomposed && outside_domain(h, a)) {
+          cross_facet(h, c, tally);
+          if (kQueue && c.decomposed && outside_domain(h, c)) {
             /* into another rank's cells: the history waits to be sent (its RNG counter
              * travels in the record) */
-            store_record(h, a, a.rec[pid], kRecEmigrate);
-            a.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, a.tiles_x, a.tile_shift);
-            atomicAdd(a.emigrants, 1u);
+            store_record(h, c, c.rec[pid], kRecEmigrate);
+            c.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, c.tiles_x, c.tile_shift);
+            atomicAdd(c.emigrants, 1u);
             want = kWantRefill;
           } else {
             next_event(true);
@@ -652,9 +688,9 @@ void history_regroup_kernel(SolveArgs a) {
         } else {
           if (h.ev == kEvCensus) {
             ncensus++;
-            census(h, a, tally);
+            census(h, c, tally);
           }
-          put_back<kQueue>(h, a, pid); /* kEvEnd: the loop at :134 simply exits */
+          put_back<kQueue>(h, c, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
         }
       }
