@@ -86,7 +86,9 @@ struct State {
   /* per-device scratch, created on first use */
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
-  unsigned long long* d_check = nullptr;            /* 4 words of tables_check_kernel */
+  unsigned long long* d_check = nullptr;            /* tables_check_kernel's words; [4], [5]:
+                                                       unphysical table entries / densities */
+  bool warned_unphysical = false;
   neutral::ParticleView* d_export_view = nullptr;   /* the stepped store's array pointers */
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   unsigned short* d_index_fine = nullptr;           /* finer index of the collision stage */
@@ -167,7 +169,8 @@ void ensure_scratch() {
   }
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
   HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
-  HIP_CHECK(hipMalloc((void**)&g.d_check, 4 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMalloc((void**)&g.d_check, 8 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMemset(g.d_check, 0, 8 * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
   HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));
   g.tables.valid = false; /* its indexes live in the other device's scratch */
@@ -854,6 +857,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
   }
 
+  if (!g.warned_unphysical && pad == 0) { /* (halo cells of a padded mesh hold anything) */
+    /* is every density what the fast arithmetic assumes?  Asked every step, like the
+     * tables (a pass over nx * ny doubles: microseconds), read with the step's counters */
+    HIP_CHECK(neutral::launch_unphysical_values(density, (long long)nx * ny, g.d_check + 5,
+                                                g.stream));
+  }
+
   neutral::StepCounters hc[2];
   unsigned ctrl[16] = {0};
   int passes = 0;
@@ -941,13 +951,24 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
     /* the one wait of a steady-state step: counters, the pipeline's control words
      * and the verdict on the table view */
-    unsigned long long check[4] = {0, 0, 0, 0};
+    unsigned long long check[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
     HIP_CHECK(hipMemcpyAsync(check, g.d_check, sizeof(check), hipMemcpyDeviceToHost, g.stream));
     if (tiled) {
       HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
     }
     wait_for_stream();
+    if ((check[4] | check[5]) != 0 && !g.warned_unphysical && !neutral::checked_ranges_build()) {
+      g.warned_unphysical = true;
+      fprintf(stderr,
+              "libneutral_hip: warning: %s%s%s not positive and finite.  This build leaves out the "
+              "range tests of its fast arithmetic, which assume they are (the reference itself "
+              "computes 0/0 there); results in such cells or at such energies may differ from "
+              "the reference's.  Build with -DNEUTRAL_CHECKED_RANGES=1 (INTEGRATION.md) for "
+              "such input.\n",
+              check[5] ? "the density of some cells is" : "", (check[4] && check[5]) ? " and " : "",
+              check[4] ? "some cross-section table entries are" : "");
+    }
     /* (several ranks take every decision that leads to another exchange together:
      * the collectives must pair up) */
     if (!(decomposed ? check[0] != 0 : any_rank(check[0] != 0))) {

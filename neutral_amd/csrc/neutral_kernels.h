@@ -243,6 +243,13 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
  * out[0] = 1 unless hash(scatter keys) == expect_hash_s, hash(absorb keys) ==
  * expect_hash_a and (tables element-wise identical) == expect_same; out[1], out[2] =
  * the two hashes, out[3] = the identity flag (all four words are written). */
+/* out[0] |= 1 when a value is not positive, finite and inside [2^-300, 2^300) */
+hipError_t launch_unphysical_values(const double* v, long long n, unsigned long long* out,
+                                    hipStream_t stream);
+/* was the library built with NEUTRAL_CHECKED_RANGES (range tests around every fast path)? */
+bool checked_ranges_build();
+/* out: 8 words -- [0] verdict, [1..3] hashes and identity, [4] |= 1 when a key or value is
+ * not physical (sticky: the caller clears it) */
 hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
                                const double* va, int na, unsigned long long expect_hash_s,
                                unsigned long long expect_hash_a, int expect_same,

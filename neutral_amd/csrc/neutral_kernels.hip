@@ -34,11 +34,13 @@ namespace neutral {
 constexpr int kBlock = 256;
 
 /* minimum resident waves per SIMD the register allocator must leave room for
- * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  K2
- * needs ~165 without spilling.  Both instantiations run at 3: the kernel is bound
- * by vector issue, and at 4 waves the spills (96 B of scratch since the state kept
- * per history grew) cost variant 1 6-20 % (profiles/r01g/baseline_configs.log;
- * the collision stage ran exactly as fast at 4 as at 3 when it spilled 56 B). */
+ * (second __launch_bounds__ argument): 3 <=> at most 168 VGPRs, 4 <=> 128.  Variant 1
+ * (K2 over the SoA store) needs ~165 without spilling and runs at 3: at 4 waves its
+ * spills cost 6-20 % (profiles/r01g/baseline_configs.log).  The collision stage of the
+ * tiled pipeline with identical tables and no flux tally -- the default -- needs 139
+ * since the range tests that cannot fire left the event bodies, and runs at 4 with 28 B
+ * of scratch in cold paths (-2.5 % against 3 waves); its other instantiations (two
+ * distinct tables, scalar flux: 143-150 VGPRs) stay at 3. */
 #ifndef NEUTRAL_K1_WAVES
 #define NEUTRAL_K1_WAVES 3
 #endif
@@ -749,6 +751,40 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
   return x;
 }
 
+/* positive, finite, and far enough from the ends of the exponent range that the event
+ * bodies' unwrapped arithmetic is exact on it (neutral_device.h: sqrt_of_physical) */
+__device__ __forceinline__ bool is_physical(double v) {
+  return (v > 0.0) & in_plain_division_range(v);
+}
+
+/* out[0] = 1 if any of n values is not (the default build's fast arithmetic assumes they
+ * all are; the host says so once, loudly, and names the checked build) */
+__global__ __launch_bounds__(1024) void unphysical_values_kernel(const double* v, long long n,
+                                                                 unsigned long long* out) {
+  const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+  const bool odd = (i < n) && !is_physical(v[i]);
+  if (__ballot(odd) != 0 && (threadIdx.x & 63) == 0) {
+    atomicOr(out, 1ull);
+  }
+}
+
+hipError_t launch_unphysical_values(const double* v, long long n, unsigned long long* out,
+                                    hipStream_t stream) {
+  if (n > 0) {
+    hipLaunchKernelGGL(unphysical_values_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0,
+                       stream, v, n, out);
+  }
+  return hipGetLastError();
+}
+
+bool checked_ranges_build() {
+#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
+  return true;
+#else
+  return false;
+#endif
+}
+
 __global__ __launch_bounds__(1024) void tables_check_kernel(
     const double* ks, const double* vs, int ns, const double* ka, const double* va, int na,
     unsigned long long expect_hash_s, unsigned long long expect_hash_a, int expect_same,
@@ -757,6 +793,16 @@ __global__ __launch_bounds__(1024) void tables_check_kernel(
   __shared__ int s_diff[16];
   unsigned long long hs = 0, ha = 0;
   int diff = (ns != na) ? 1 : 0;
+  bool odd = false; /* a key or a value the unwrapped arithmetic is not exact on */
+  for (int i = threadIdx.x; i < ns; i += 1024) {
+    odd = odd || !is_physical(ks[i]) || !is_physical(vs[i]);
+  }
+  for (int i = threadIdx.x; i < na; i += 1024) {
+    odd = odd || !is_physical(ka[i]) || !is_physical(va[i]);
+  }
+  if (__ballot(odd) != 0 && (threadIdx.x & 63) == 0) {
+    atomicOr(&out[4], 1ull);
+  }
   for (int i = threadIdx.x; i < ns; i += 1024) {
     const unsigned long long k = (unsigned long long)__double_as_longlong(ks[i]);
     hs += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
