@@ -253,7 +253,7 @@ constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is pl
 #define NEUTRAL_QUEUE_CHUNK_MIN 8
 #endif
 #ifndef NEUTRAL_REFILL_MIN
-#define NEUTRAL_REFILL_MIN 4
+#define NEUTRAL_REFILL_MIN 3
 #endif
 #ifndef NEUTRAL_COLLIDE_MIN
 #define NEUTRAL_COLLIDE_MIN 48
