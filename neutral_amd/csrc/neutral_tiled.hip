@@ -322,32 +322,47 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
  * a collision, for the collision kernel */
 __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs a, TiledArgs t,
                                                                        const unsigned* info) {
-  /* one queue reservation per workgroup: a returning atomic on a single word
-   * takes ~100 ops/us, and every history of a collision-only deck is suspended */
-  __shared__ unsigned s_count[kSortBlock / 64];
+  /* one queue reservation per segment of kSortSegment records: a returning atomic on a
+   * single word takes ~100 ops/us, and every history of a collision-only deck is
+   * suspended (scatter 1e8: one per 256 records cost 3.9 ms of atomics) */
+  __shared__ unsigned s_count[kSortItems][kSortBlock / 64];
   __shared__ unsigned s_base;
-  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  const long long base = (long long)blockIdx.x * kSortSegment;
   const int wave = threadIdx.x >> 6;
-  const bool susp = i < t.sort_end && summary_state(info[i]) == kRecCollide;
-  const unsigned long long m = __ballot(susp);
-  if ((threadIdx.x & 63) == 0) {
-    s_count[wave] = (unsigned)__popcll(m);
+  unsigned mine = 0; /* bit k: record base + k * kSortBlock + threadIdx.x is suspended */
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    const long long i = base + (long long)k * kSortBlock + threadIdx.x;
+    const bool susp = i < t.sort_end && summary_state(info[i]) == kRecCollide;
+    const unsigned long long m = __ballot(susp);
+    mine |= susp ? (1u << k) : 0u;
+    if ((threadIdx.x & 63) == 0) {
+      s_count[k][wave] = (unsigned)__popcll(m);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned total = 0;
-    for (int w = 0; w < kSortBlock / 64; ++w) {
-      total += s_count[w];
+    unsigned total = 0; /* exclusive prefix over (item, wave), in place */
+    for (int k = 0; k < kSortItems; ++k) {
+      for (int w = 0; w < kSortBlock / 64; ++w) {
+        const unsigned c = s_count[k][w];
+        s_count[k][w] = total;
+        total += c;
+      }
     }
     s_base = total ? atomicAdd(&t.ctrl[kCtrlCollideCount], total) : 0u;
   }
   __syncthreads();
-  if (susp) {
-    unsigned before = 0;
-    for (int w = 0; w < wave; ++w) {
-      before += s_count[w];
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+      const bool susp = ((mine >> k) & 1u) != 0;
+      const unsigned long long m = __ballot(susp);
+      if (susp) {
+        t.collide_queue[s_base + s_count[k][wave] + (unsigned)lane_rank(m)] =
+            (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+      }
     }
-    t.collide_queue[s_base + before + (unsigned)lane_rank(m)] = (unsigned)i;
   }
 }
 
@@ -1212,7 +1227,6 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     t.sort_end = a.nparticles; /* (no graveyard: slots come and go within a step) */
     t.mirror_end = a.nparticles;
   }
-  const int grid_n = t.sort_end > 0 ? (t.sort_end + kSortBlock - 1) / kSortBlock : 1;
   int dev = 0;
   int cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1243,8 +1257,9 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
 
   /* 3. the suspended histories: K2 over the collision queue; it counts its
    * events in the second StepCounters record */
-  hipLaunchKernelGGL(collect_suspended_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t,
-                     t.info_out);
+  hipLaunchKernelGGL(collect_suspended_kernel,
+                     dim3(t.sort_end > 0 ? (t.sort_end + kSortSegment - 1) / kSortSegment : 1),
+                     dim3(kSortBlock), 0, stream, a, t, t.info_out);
   if (after_collect) {
     (void)hipEventRecord(after_collect, stream);
   }
