@@ -280,7 +280,8 @@ __device__ __forceinline__ double log_core(double x, int k_scaled) {
   m = low ? m + m : m; /* [sqrt(1/2), sqrt(2)) */
   k = low ? k - 1 : k;
   const double f = m - 1.0; /* exact */
-  const double s = f / (2.0 + f);
+  /* (f is +0 or 1e-16 ... 0.41 in magnitude, 2 + f is 1.7 ... 2.41: plain operands) */
+  const double s = quotient_of_physical(f, 2.0 + f);
   const double z = s * s;
   double r = 2.0 / 21.0;
   r = __builtin_fma(r, z, 2.0 / 19.0);
