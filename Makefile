@@ -2,9 +2,17 @@
 all:
 	python -c "import __graft_entry__ as g; g.build()"
 
-# the whole CPU suite, the five-minute scatter known answer included
+# the whole CPU suite, the five-minute scatter known answer included.  The log goes to an
+# untracked file and the recipe fails when pytest does; `make pin-kats` makes the run the
+# tracked record oracle/pins/full_kats.log.
+SHELL := /bin/bash
 test-cpu: all
-	NEUTRAL_FULL_KATS=1 python -m pytest tests -x -q -m "not gpu" 2>&1 | tee oracle/pins/full_kats.log
+	set -o pipefail; NEUTRAL_FULL_KATS=1 python -m pytest tests -x -q -rA -m "not gpu" 2>&1 | tee oracle/pins/_latest.log
+
+pin-kats: test-cpu
+	{ echo "# make test-cpu at $$(git rev-parse --short HEAD)$$(git diff --quiet || echo +dirty), $$(date -u +%Y-%m-%dT%H:%MZ)"; \
+	  echo "# oracle/neutral_oracle.c sha256 $$(sha256sum oracle/neutral_oracle.c | cut -c1-16)"; \
+	  grep -E "PASSED|FAILED|SKIPPED|passed|failed" oracle/pins/_latest.log; } > oracle/pins/full_kats.log
 
 test-gpu: all
 	python -m pytest tests -x -q -m gpu
@@ -17,4 +25,4 @@ clean:
 	$(MAKE) -C oracle clean
 	rm -rf integration/_dropin
 
-.PHONY: all test-cpu test-gpu bench clean
+.PHONY: all test-cpu pin-kats test-gpu bench clean

@@ -13,4 +13,4 @@ Importing the package does not load the HIP library; ``neutral_amd.interface``
 does, and fails loudly when it has not been built.
 """
 
-__all__ = ["decks", "cs_table", "host", "interface", "build"]
+__all__ = ["decks", "cs_table", "host", "interface", "shard"]

@@ -88,11 +88,16 @@ bool load_rccl(Rccl& r) {
   return r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy && r.GetErrorString;
 }
 
+/* The helper thread owns its job record, the communicator slot included: only the
+ * waiting thread publishes job->comm to c.comm, and only after the helper said it is
+ * done.  A helper that outlives its time limit keeps the record (it is never freed and
+ * its communicator never destroyed: it may still be half-way through the bring-up). */
 struct InitJob {
   ncclUniqueId id;
   int rank;
   int nranks;
   int device;
+  ncclComm_t comm;
   ncclResult_t result;
   volatile int done;
 };
@@ -100,7 +105,7 @@ struct InitJob {
 void* init_thread(void* arg) {
   InitJob* j = (InitJob*)arg;
   (void)hipSetDevice(j->device);
-  j->result = c.rccl.CommInitRank(&c.comm, j->nranks, j->id, j->rank);
+  j->result = c.rccl.CommInitRank(&j->comm, j->nranks, j->id, j->rank);
   __atomic_store_n(&j->done, 1, __ATOMIC_RELEASE);
   return nullptr;
 }
@@ -276,6 +281,7 @@ int neutral_hip_comm_start(void) {
     }
     comms_bcast_bytes(&job->id, sizeof(job->id));
     ok = everybody(ok);
+    bool timed_out = false;
     if (ok) {
       job->rank = rank;
       job->nranks = nranks;
@@ -292,7 +298,9 @@ int neutral_hip_comm_start(void) {
           if (__atomic_load_n(&job->done, __ATOMIC_ACQUIRE)) {
             pthread_join(th, nullptr);
             ok = job->result == ncclSuccess;
-            if (!ok) {
+            if (ok) {
+              c.comm = job->comm; /* published here, by the thread that uses it */
+            } else {
               fprintf(stderr, "libneutral_hip: rank %d: ncclCommInitRank failed: %s\n", rank,
                       c.rccl.GetErrorString(job->result));
             }
@@ -302,16 +310,27 @@ int neutral_hip_comm_start(void) {
           clock_gettime(CLOCK_MONOTONIC, &t);
           if ((t.tv_sec - t0.tv_sec) > limit_s) {
             /* the thread is left behind with its job record (it cannot be cancelled
-             * safely); this rank goes on without RCCL */
+             * safely, and nothing of the record is touched again from here) */
             fprintf(stderr, "libneutral_hip: rank %d: RCCL did not come up within %d s.\n", rank,
                     limit_s);
             pthread_detach(th);
             ok = false;
+            timed_out = true;
             break;
           }
           struct timespec nap = {0, 2000000};
           nanosleep(&nap, nullptr);
         }
+      }
+      /* A bring-up that FAILED leaves nothing behind: every rank falls back to the host
+       * route.  One that TIMED OUT leaves a thread inside RCCL on this rank and, on the
+       * ranks where it succeeded, a communicator joined by a peer that gave up: the job
+       * ends here, on every rank, instead of running on next to that. */
+      if (!everybody(!timed_out)) {
+        fprintf(stderr, "libneutral_hip: rank %d: the RCCL bring-up timed out on some rank; "
+                        "set NEUTRAL_HIP_COMM=host to stage the exchange through the hosts, or "
+                        "raise NEUTRAL_COMM_TIMEOUT.\n", rank);
+        _exit(EXIT_FAILURE);
       }
       ok = everybody(ok);
     } else {

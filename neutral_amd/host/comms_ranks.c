@@ -67,6 +67,30 @@ static void recv_all(int fd, void* buf, size_t n) {
   }
 }
 
+/* n bytes or nothing: 0 when the peer closed, timed out (SO_RCVTIMEO) or failed --
+ * for the handshake, where a stray connection is dropped rather than fatal */
+static int recv_or_give_up(int fd, void* buf, size_t n) {
+  char* p = (char*)buf;
+  while (n) {
+    const ssize_t k = recv(fd, p, n, 0);
+    if (k <= 0) {
+      if (k < 0 && errno == EINTR) continue;
+      return 0;
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+  return 1;
+}
+
+/* what a rank says when it connects: a word the launcher hands to all its ranks
+ * (NEUTRAL_COMM_NONCE; neutral.hip --gpus and bench.py draw a random one), so that a
+ * process that merely finds the port cannot claim a rank, and the rank id */
+static unsigned long long handshake_nonce(void) {
+  const char* v = getenv("NEUTRAL_COMM_NONCE");
+  return (v && *v) ? strtoull(v, NULL, 0) : 0x6e65757472616cull; /* "neutral" */
+}
+
 static int env_int(const char* name, int fallback) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : fallback;
@@ -117,7 +141,9 @@ void comms_start_from_env(void) {
   g_peer = (int*)calloc((size_t)g_nranks, sizeof(int));
   if (g_rank == 0) {
     const int ls = socket(AF_INET, SOCK_STREAM, 0);
-    setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    if (ls >= 0) {
+      setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    }
     if (ls < 0 || bind(ls, (struct sockaddr*)&sa, sizeof(sa)) != 0 || listen(ls, g_nranks) != 0) {
       TERMINATE("rank 0 cannot listen on %s:%d (%s); set NEUTRAL_COMM_PORT.\n", addr, port,
                 strerror(errno));
@@ -134,15 +160,20 @@ void comms_start_from_env(void) {
         continue;
       }
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      /* (the accept timeout of the listening socket must not carry over: a rank may
-       * be silent for as long as its GPU is busy) */
+      /* the handshake keeps a receive timeout: a stray or half-open connection to the
+       * port (or one that does not know the launcher's word, or names a rank that is
+       * taken) is dropped and the wait for the real ranks goes on */
+      struct timeval hs = {5, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hs, sizeof(hs));
+      unsigned long long hello[2] = {0, 0};
+      const int who = recv_or_give_up(fd, hello, sizeof(hello)) ? (int)hello[1] : -1;
+      if (hello[0] != handshake_nonce() || who < 1 || who >= g_nranks || g_peer[who]) {
+        close(fd);
+        continue;
+      }
+      /* (from here on no timeout: a rank may be silent for as long as its GPU is busy) */
       struct timeval forever = {0, 0};
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &forever, sizeof(forever));
-      int who = -1;
-      recv_all(fd, &who, sizeof(who));
-      if (who < 1 || who >= g_nranks || g_peer[who]) {
-        TERMINATE("rank 0: a peer announced itself as rank %d of %d.\n", who, g_nranks);
-      }
       g_peer[who] = fd;
       joined++;
     }
@@ -162,7 +193,8 @@ void comms_start_from_env(void) {
       usleep(20000);
     }
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-    send_all(fd, &g_rank, sizeof(g_rank));
+    const unsigned long long hello[2] = {handshake_nonce(), (unsigned long long)g_rank};
+    send_all(fd, hello, sizeof(hello));
     g_peer[0] = fd;
   }
   comms_barrier(); /* everybody is connected before anybody goes on */

@@ -115,6 +115,17 @@ static void fork_ranks(int nranks) {
   setenv("MASTER_PORT", buf, 1);
   snprintf(buf, sizeof(buf), "%d", nranks);
   setenv("WORLD_SIZE", buf, 1);
+  if (!getenv("NEUTRAL_COMM_NONCE")) {
+    /* the word the ranks of THIS launch greet rank 0 with (comms_ranks.c) */
+    unsigned long long nonce = ((unsigned long long)getpid() << 32) ^ (unsigned long long)time(NULL);
+    FILE* rnd = fopen("/dev/urandom", "rb");
+    if (rnd) {
+      if (fread(&nonce, sizeof(nonce), 1, rnd) != 1) { /* keep the fallback */ }
+      fclose(rnd);
+    }
+    snprintf(buf, sizeof(buf), "%llu", nonce);
+    setenv("NEUTRAL_COMM_NONCE", buf, 1);
+  }
   pid_t kids[64];
   for (int r = 0; r < nranks; ++r) {
     fflush(stdout);

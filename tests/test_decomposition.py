@@ -1,10 +1,13 @@
 """Spatial domain decomposition on a real GPU (`-m gpu`): N ranks (processes sharing
 the one GPU of the test box, particle exchange staged through the host) each own a
 block of the mesh; histories cross between the blocks within a timestep.  Whatever
-the grid of ranks, every particle must end where the undecomposed run puts it, bit
-for bit (keys are global ids, the RNG counter travels with the history), the event
-totals must be exact and the blocks of the tally must add up to the undecomposed
-tally."""
+the grid of ranks, the assembled result is compared FIRST WITH THE CPU ORACLE on the
+same deck (undecomposed, one rank: per-step event counts exact, cells and death flags
+exact by global id, floating state 1e-9, per-cell tally L2 1e-9, equal zero pattern --
+the bars of tests/test_hip_parity.py) and then, as a second assertion, with the
+undecomposed HIP run, where every particle must end bit for bit where that run puts
+it (keys are global ids, the RNG counter travels with the history) and the blocks of
+the tally must add up to its tally."""
 import json
 import os
 import socket
@@ -14,6 +17,7 @@ import sys
 import numpy as np
 import pytest
 
+import oracle_binding as ob
 from conftest import ROOT, gpu_available
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
@@ -63,6 +67,49 @@ def _reference(make_problem_deck, cs, steps, flux=False):
     return out
 
 
+STATE_TOL = 1e-9      # tests/test_hip_parity.py
+TALLY_L2_TOL = 1e-9   # north-star bar: 1e-6
+
+
+def _oracle(deck_path, cs, steps, flux=False):
+    """The CPU oracle on the whole mesh, one rank (omp3/neutral.c:19-206)."""
+    from neutral_amd import host
+    prob = host.setup_problem(deck_path)
+    ref = ob.OracleRun(prob, *cs, scalar_flux=flux)
+    ref.inject()
+    ev = []
+    for tt in range(1, steps + 1):
+        r = ref.step(tt)
+        ev.append((r.nprocessed, r.facets, r.collisions, r.census))
+    return (ref.particles.as_dict(), ref.tally.reshape(prob.ny, prob.nx),
+            ref.flux.reshape(prob.ny, prob.nx) if flux else None, ev)
+
+
+def _rel(a, b):
+    d = np.abs(a - b)
+    s = np.maximum(np.abs(b), 1e-300)
+    return float(np.max(d / s)) if a.size else 0.0
+
+
+def _assert_state_matches_oracle(got, ids, want):
+    """got: arrays of the particles with global ids `ids`; want: the oracle's, by id."""
+    k = np.asarray(ids).astype(np.int64)
+    for f in ("cellx", "celly", "dead"):
+        assert np.array_equal(got[f], want[f][k]), f
+    for f in ("energy", "weight", "dt_to_census", "x", "y"):
+        assert _rel(got[f], want[f][k]) < STATE_TOL, f
+    for f in ("omega_x", "omega_y"):
+        assert np.max(np.abs(got[f] - want[f][k]), initial=0.0) < STATE_TOL, f
+    scale = max(1e-300, float(np.max(np.abs(want["mfp_to_collision"]))))
+    assert np.max(np.abs(got["mfp_to_collision"] - want["mfp_to_collision"][k]),
+                  initial=0.0) / scale < STATE_TOL
+
+
+def _assert_mesh_matches_oracle(got, want):
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < TALLY_L2_TOL
+    assert np.array_equal(got == 0.0, want == 0.0)
+
+
 FIELDS = ("x", "y", "omega_x", "omega_y", "energy", "weight", "dt_to_census", "mfp_to_collision",
           "cellx", "celly", "dead")
 
@@ -80,8 +127,20 @@ def test_decomposed_run_equals_the_undecomposed_one(tmp_path, cs, deck, nx, n, d
     if dt is not None:
         kw["dt"] = dt
     path = decks.write_deck(deck, str(tmp_path / f"{deck}.params"), **kw)
+    orc_p, orc_t, _, orc_ev = _oracle(path, cs, steps)
     want_p, want_t, _, want_ev, prob = _reference(path, cs, steps)
     ranks, logs = _run_ranks(path, str(tmp_path), steps, px, py)
+
+    # ---- first: against the CPU oracle (undecomposed, one rank) ----
+    got = np.zeros_like(orc_t)
+    for r in ranks:
+        xo, yo, lx, ly = r["block"]
+        assert [tuple(e) for e in r["events"]] == orc_ev
+        _assert_state_matches_oracle(r, r["ids"], orc_p)
+        got[yo:yo + ly, xo:xo + lx] += r["tally"].reshape(ly, lx)
+    _assert_mesh_matches_oracle(got, orc_t)
+
+    # ---- second: bit identity with the undecomposed HIP run ----
 
     # every particle is on exactly one rank, in the block it sits in, with the state the
     # undecomposed run gives it
@@ -113,6 +172,7 @@ def test_decomposed_run_with_the_scalar_flux(tmp_path, cs):
     from neutral_amd import decks
     path = decks.write_deck("csp", str(tmp_path / "csp.params"), nx=100, ny=100, nparticles=30000,
                             iterations=2, dt=1.0e-6)
+    orc_p, orc_t, orc_f, orc_ev = _oracle(path, cs, 2, flux=True)
     _, want_t, want_f, want_ev, _ = _reference(path, cs, 2, flux=True)
     ranks, _ = _run_ranks(path, str(tmp_path), 2, 2, 2, extra=("flux",))
     got_t, got_f = np.zeros_like(want_t), np.zeros_like(want_f)
@@ -120,7 +180,11 @@ def test_decomposed_run_with_the_scalar_flux(tmp_path, cs):
         xo, yo, lx, ly = r["block"]
         got_t[yo:yo + ly, xo:xo + lx] += r["tally"].reshape(ly, lx)
         got_f[yo:yo + ly, xo:xo + lx] += r["flux"].reshape(ly, lx)
+        assert [tuple(e) for e in r["events"]] == orc_ev
         assert [tuple(e) for e in r["events"]] == want_ev
+        _assert_state_matches_oracle(r, r["ids"], orc_p)
+    _assert_mesh_matches_oracle(got_t, orc_t)
+    _assert_mesh_matches_oracle(got_f, orc_f)
     assert np.linalg.norm(got_t - want_t) / np.linalg.norm(want_t) < 1e-13
     assert np.linalg.norm(got_f - want_f) / np.linalg.norm(want_f) < 1e-13
 
@@ -131,10 +195,17 @@ def test_sharded_ranks_with_the_scalar_flux(tmp_path, cs):
     from neutral_amd import decks
     path = decks.write_deck("csp", str(tmp_path / "csp.params"), nx=100, ny=100, nparticles=30001,
                             iterations=2, dt=1.0e-6)
+    orc_p, orc_t, orc_f, orc_ev = _oracle(path, cs, 2, flux=True)
     want_p, want_t, want_f, want_ev, _ = _reference(path, cs, 2, flux=True)
     ranks, _ = _run_ranks(path, str(tmp_path), 2, 3, 1, mode="shard", extra=("flux",))
     assert sum(len(r["ids"]) for r in ranks) == 30001
     for r in ranks:
+        # against the oracle: every rank holds the all-reduced global meshes
+        assert [tuple(e) for e in r["events"]] == orc_ev
+        _assert_state_matches_oracle(r, r["ids"], orc_p)
+        _assert_mesh_matches_oracle(r["tally"].reshape(100, 100), orc_t)
+        _assert_mesh_matches_oracle(r["flux"].reshape(100, 100), orc_f)
+        # and against the one-rank HIP run
         assert [tuple(e) for e in r["events"]] == want_ev
         assert np.linalg.norm(r["tally"].reshape(100, 100) - want_t) / np.linalg.norm(want_t) < 1e-12
         assert np.linalg.norm(r["flux"].reshape(100, 100) - want_f) / np.linalg.norm(want_f) < 1e-12

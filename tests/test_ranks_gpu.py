@@ -3,13 +3,17 @@ forks one process per rank before anything touches the GPU; the library shards t
 particles, every rank steps its shard, and solve_transport_2d ends each timestep
 with the all-reduce of the tally.  The test box has ONE GPU, so the ranks share it
 (NEUTRAL_HIP_SHARE_DEVICE) and the exchange is staged through the host; RCCL itself
-is exercised with a one-rank communicator (load, init, all-reduce on the device)."""
+is exercised with a one-rank communicator (load, init, all-reduce on the device).
+Every multi-rank run is compared first with the CPU oracle on the same deck (one rank,
+whole mesh: per-step event counts exact, the global tally to 1e-10) and then with the
+one-rank HIP run."""
 import os
 import re
 import subprocess
 
 import pytest
 
+import oracle_binding as ob
 from conftest import ROOT, gpu_available
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
@@ -40,9 +44,35 @@ def _numbers(stdout):
     return facets, colls, parts, tally
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_numbers(tmp_path, cs, **overrides):
+    """(facets, collisions, particles) per step and the global tally of the CPU oracle
+    (oracle/neutral_oracle.c, restating omp3/neutral.c:19-206) on the csp deck."""
+    from neutral_amd import decks, host
+    key = tuple(sorted(overrides.items()))
+    if key not in _ORACLE_CACHE:
+        path = decks.write_deck("csp", str(tmp_path / "oracle_csp.params"), **overrides)
+        prob = host.setup_problem(path, 1.0, 1.0)
+        ref = ob.OracleRun(prob, *cs)
+        ref.inject()
+        f, c, p = [], [], []
+        for tt in range(1, overrides["iterations"] + 1):
+            r = ref.step(tt)
+            f.append(r.facets)
+            c.append(r.collisions)
+            p.append(r.nprocessed)
+        _ORACLE_CACHE[key] = (f, c, p, ref.tally_sum())
+    return _ORACLE_CACHE[key]
+
+
+CSP_128 = dict(nx=128, ny=128, nparticles=200001, iterations=4, dt=1.0e-6)
+
+
 @pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
 @pytest.mark.parametrize("nranks,comm", [(2, "host"), (3, "host"), (2, "rccl")])
-def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, nranks, comm):
+def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, cs, nranks, comm):
     """csp at 128^2 with 200 001 particles (not divisible by the rank count), 4 steps:
     every step's global event counts are exact, the tally agrees to summation order.
     comm = rccl on a shared device: ncclCommInitRank refuses the duplicate GPU, every
@@ -64,6 +94,9 @@ def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, nranks, comm):
     many, err = _run_driver(str(run), rel, sets + ["--gpus", str(nranks)], env)
     f1, c1, p1, t1 = _numbers(one)
     fn, cn, pn, tn = _numbers(many)
+    fo, co, po, to = _oracle_numbers(tmp_path, cs, **CSP_128)
+    assert (fo, co, po) == (fn, cn, pn), many[-1500:]      # the oracle first
+    assert abs(tn - to) <= 1e-10 * abs(to)
     assert (f1, c1, p1) == (fn, cn, pn), (one[-1500:], many[-1500:])
     assert len(f1) == 4
     assert abs(tn - t1) <= 1e-12 * abs(t1)
@@ -73,7 +106,7 @@ def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, nranks, comm):
 
 @pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
 @pytest.mark.parametrize("nranks,grid", [(2, "2x1"), (4, "2x2")])
-def test_forked_ranks_with_a_decomposed_mesh(tmp_path, nranks, grid):
+def test_forked_ranks_with_a_decomposed_mesh(tmp_path, cs, nranks, grid):
     """`neutral.hip --gpus N --decompose PXxPY`: every rank holds a block of the mesh and
     the particles inside it; histories cross between the blocks within the step.  Event
     counts as in the one-rank run, exactly; the tally (summed over the blocks by
@@ -95,5 +128,8 @@ def test_forked_ranks_with_a_decomposed_mesh(tmp_path, nranks, grid):
                             env)
     f1, c1, p1, t1 = _numbers(one)
     fn, cn, pn, tn = _numbers(many)
+    fo, co, po, to = _oracle_numbers(tmp_path, cs, **CSP_128)
+    assert (fo, co, po) == (fn, cn, pn), many[-1500:]      # the oracle first
+    assert abs(tn - to) <= 1e-10 * abs(to)
     assert (f1, c1, p1) == (fn, cn, pn), (one[-1500:], many[-1500:])
     assert abs(tn - t1) <= 1e-12 * abs(t1)

@@ -1,6 +1,8 @@
-"""N > 1 host path on CPU: two gloo ranks, each advancing its particle shard
-(the CPU oracle stands in for the kernels), one tally all-reduce per timestep
-through neutral_amd.shard -- must reproduce the unsharded run."""
+"""N > 1 on CPU with torch.distributed: two gloo ranks, each advancing its particle
+shard (the CPU oracle stands in for the kernels; the partition is the product's
+neutral_amd.shard.shard_range), one tally all-reduce per timestep -- must reproduce the
+unsharded run.  (The product's own exchange is C inside libneutral_hip.so; its CPU
+tests are tests/test_comms_ranks.py and tests/test_shard_ranks_cpu.py.)"""
 import os
 import sys
 
@@ -10,7 +12,30 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from neutral_amd.shard import StepTallyExchange, shard_range
+from neutral_amd.shard import shard_range
+
+
+class StepTallyExchange:
+    """Test-only: the per-step exchange as torch.distributed would do it.  Each rank's
+    "kernels" add into `step_tally` (zeroed at the start of the step); finish_step()
+    all-reduces it and accumulates it into `tally`, which then holds the same global
+    mesh on every rank."""
+
+    def __init__(self, tally, world_size: int):
+        self.tally = tally
+        self.world_size = world_size
+        self.step_tally = tally if world_size == 1 else tally.new_zeros(tally.shape)
+
+    def begin_step(self):
+        if self.world_size > 1:
+            self.step_tally.zero_()
+        return self.step_tally
+
+    def finish_step(self):
+        if self.world_size > 1:
+            dist.all_reduce(self.step_tally, op=dist.ReduceOp.SUM)
+            self.tally += self.step_tally
+        return self.tally
 
 
 def test_shard_range_partitions_exactly():
@@ -25,6 +50,22 @@ def test_shard_range_partitions_exactly():
             assert max(counts) - min(counts) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_shard_range_is_the_c_rank_layers_partition():
+    """neutral_amd.shard.shard_range == comms_shard_range (host/comms_ranks.c), which is
+    what inject_particles cuts a rank's share with."""
+    import ctypes as C
+    from neutral_amd import host
+    L = host.lib()
+    L.comms_shard_range.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_longlong),
+                                    C.POINTER(C.c_longlong)]
+    for n in (0, 1, 7, 200001, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                first, count = C.c_longlong(), C.c_longlong()
+                L.comms_shard_range(n, r, world, C.byref(first), C.byref(count))
+                assert (first.value, count.value) == shard_range(n, r, world)
 
 
 def _worker(rank, world, port, deck_path, out_dir):

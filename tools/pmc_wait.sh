@@ -9,7 +9,7 @@ D="SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR 
 rm -rf /tmp/pmcw_$tag
 rocprofv3 --pmc $C -d /tmp/pmcw_$tag/c --output-format csv -- python3 $R/tools/ablate.py "$@" > /tmp/pmcw_$tag.c.log 2>&1
 rocprofv3 --pmc $D -d /tmp/pmcw_$tag/d --output-format csv -- python3 $R/tools/ablate.py "$@" > /tmp/pmcw_$tag.d.log 2>&1
-python3 - "$tag" "$@" <<'PY' | tee $R/gpurun_out/pmc_wait_$1.txt
+python3 - "$tag" "$@" <<'PY' | tee $R/gpurun_out/pmc_wait_$tag.txt
 import csv, glob, sys, collections
 tag = sys.argv[1]
 allk = collections.defaultdict(lambda: collections.defaultdict(float))
