@@ -180,6 +180,12 @@ typedef struct {
   int tile_cells;       /* tiled variant: tile edge chosen for the problem (16..128 cells) */
   double export_ms;     /* tiled variant, default mode: HIP-event time of the write-back of
                            the records to the SoA arrays (not part of kernel_ms) */
+  int checked_arithmetic; /* 1: the step ran the kernels instantiated with IEEE-checked
+                             arithmetic (an input lay outside the fast sequences' proven
+                             range: neutral_hip_set_arithmetic below); 0: the fast ones */
+  int attempts;          /* times the step's kernels were enqueued (1 in steady state; +1
+                            when the device-side check turned the attempt down: a table
+                            rewritten in place, input outside the proven range) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */
@@ -202,6 +208,20 @@ void neutral_hip_set_quiet(int quiet);
 void neutral_hip_set_tests_file(const char* path);
 /* Statistics of the most recent solve_transport_2d call. */
 void neutral_hip_last_step(NeutralHipStepStats* stats);
+/* Arithmetic of the event bodies.  Divisions, square roots and the logarithm exist in
+ * two instantiations of every history kernel that deliver the same bits wherever both
+ * are defined: bare operation sequences, proven exact when every density of the mesh
+ * and every key and value of the cross-section tables lies in [2^-100, 2^100], and
+ * IEEE-checked ones that accept whatever the reference's C accepts (a true-vacuum cell
+ * of density 0 runs on 1/0 = inf there, omp3/neutral.c:127-146,231).
+ * NEUTRAL_HIP_ARITH_AUTO (default): decided per step ON THE DEVICE from that step's
+ * density mesh and tables -- the fast kernels return at entry when the input is outside
+ * the proven range and the step runs checked; nothing to rebuild, nothing to configure.
+ * NEUTRAL_HIP_ARITH_CHECKED: always the checked kernels (also: environment variable
+ * NEUTRAL_HIP_ARITH=checked).  Returns 0 on success. */
+#define NEUTRAL_HIP_ARITH_AUTO 0
+#define NEUTRAL_HIP_ARITH_CHECKED 1
+int neutral_hip_set_arithmetic(int mode);
 /* Resets particles 0..nparticles-1 of an existing store to their injected state
  * (same arguments as inject_particles, no allocation). */
 void neutral_hip_reinject_particles(const int nparticles, const int local_nx,

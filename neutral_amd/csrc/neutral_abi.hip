@@ -27,7 +27,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 5 /* 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 6 /* 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic + attempts; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
@@ -86,9 +86,13 @@ struct State {
   /* per-device scratch, created on first use */
   int scratch_device = -1;
   neutral::StepCounters* d_counters = nullptr;
-  unsigned long long* d_check = nullptr;            /* tables_check_kernel's words; [4], [5]:
-                                                       unphysical table entries / densities */
-  bool warned_unphysical = false;
+  unsigned long long* d_check = nullptr;            /* tables_check_kernel's words
+                                                       (neutral_kernels.h: launch_tables_check) */
+  int arithmetic = NEUTRAL_HIP_ARITH_AUTO;          /* neutral_hip_set_arithmetic */
+  bool arithmetic_from_env_done = false;
+  bool use_checked = false; /* auto mode: what the last step's device-side check found ... */
+  const void* checked_density = nullptr; /* ... for this density mesh (another mesh starts fast) */
+  bool said_checked = false;
   neutral::ParticleView* d_export_view = nullptr;   /* the stepped store's array pointers */
   unsigned short* d_index[2] = {nullptr, nullptr}; /* bucketed cs indexes (scatter, absorb) */
   unsigned short* d_index_fine = nullptr;           /* finer index of the collision stage */
@@ -385,7 +389,7 @@ void before_device_write(const void* dst, size_t bytes) {
  * the tables (pointers, sizes, variant) are new -- that waits for the device -- and
  * otherwise only enqueues the device-side check of the contents. */
 void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCrossSection* cs_a,
-                        bool rebuild) {
+                        bool rebuild, bool fast_arithmetic) {
   TableView& v = g.tables;
   const bool same_args = v.valid && v.keys_s == cs_s->keys && v.values_s == cs_s->values &&
                          v.n_s == cs_s->nentries && v.keys_a == cs_a->keys &&
@@ -402,7 +406,7 @@ void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCros
     v.variant = g.variant;
     /* identity and key hashes from the check kernel itself (expectations unknown) */
     HIP_CHECK(neutral::launch_tables_check(v.keys_s, v.values_s, v.n_s, v.keys_a, v.values_a, v.n_a,
-                                           0ull, 0ull, -1, g.d_check, g.stream));
+                                           0ull, 0ull, -1, 0, g.d_check, g.stream));
     unsigned long long h[4];
     HIP_CHECK(hipMemcpyAsync(h, g.d_check, sizeof(h), hipMemcpyDeviceToHost, g.stream));
     wait_for_stream();
@@ -433,7 +437,8 @@ void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCros
   }
   /* every step: the contents against the view (result read with the step's counters) */
   HIP_CHECK(neutral::launch_tables_check(v.keys_s, v.values_s, v.n_s, v.keys_a, v.values_a, v.n_a,
-                                         v.hash_s, v.hash_a, v.same, g.d_check, g.stream));
+                                         v.hash_s, v.hash_a, v.same, fast_arithmetic ? 1 : 0,
+                                         g.d_check, g.stream));
 }
 
 neutral::ParticleView view_of(const NeutralHipParticle* p) {
@@ -733,6 +738,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   }
 
   read_variant_env();
+  if (!g.arithmetic_from_env_done) {
+    g.arithmetic_from_env_done = true;
+    const char* arith = getenv("NEUTRAL_HIP_ARITH");
+    if (arith && strcmp(arith, "checked") == 0) {
+      g.arithmetic = NEUTRAL_HIP_ARITH_CHECKED;
+    }
+  }
   ensure_scratch();
   g.host_syncs = 0;
   const bool tiled = (g.variant == NEUTRAL_HIP_VARIANT_TILED);
@@ -857,24 +869,69 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
   }
 
-  if (!g.warned_unphysical && pad == 0) { /* (halo cells of a padded mesh hold anything) */
-    /* is every density what the fast arithmetic assumes?  Asked every step, like the
-     * tables (a pass over nx * ny doubles: microseconds), read with the step's counters */
-    HIP_CHECK(neutral::launch_unphysical_values(density, (long long)nx * ny, g.d_check + 5,
-                                                g.stream));
+  /* Arithmetic policy of this step's kernels (neutral_device.h).  Auto: start from what
+   * the last step's check found; the check of THIS step's input runs on the device ahead
+   * of the kernels and turns a fast attempt down if the input is outside the proven
+   * range (the attempt then runs again, checked).  A padded mesh's halo cells hold
+   * anything, so the density check cannot speak for it: checked. */
+  if (g.checked_density != (const void*)density) {
+    g.checked_density = (const void*)density;
+    g.use_checked = false;
   }
+  bool checked = g.arithmetic == NEUTRAL_HIP_ARITH_CHECKED || g.use_checked || pad != 0;
+  bool stale_view = false;
 
   neutral::StepCounters hc[2];
   unsigned ctrl[16] = {0};
   int passes = 0;
   int same = 0;
+  int attempts = 0;
+  /* HIP-event times of the step's stages, ACCUMULATED over every batch of launches the
+   * step needs (the first enqueue, more stream passes when the step outruns the plan,
+   * the rounds of a decomposed mesh): each batch brackets itself with the same events
+   * and is harvested after the wait that follows it. */
+  struct StageMs {
+    double kernel = 0.0, sort = 0.0, stream = 0.0, collide = 0.0, exported = 0.0;
+  } stage;
+  auto harvest = [&](bool with_sort) {
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
+    stage.kernel += (double)ms;
+    if (tiled) {
+      if (with_sort) {
+        HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_sorted));
+        stage.sort += (double)ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, g.ev_sorted, g.ev_streamed));
+      } else { /* (later sorts sit inside the stream passes they serve) */
+        HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_streamed));
+      }
+      stage.stream += (double)ms;
+      HIP_CHECK(hipEventElapsedTime(&ms, g.ev_streamed, g.ev_collected));
+      stage.sort += (double)ms; /* (the collision queue's build) */
+      HIP_CHECK(hipEventElapsedTime(&ms, g.ev_collected, g.ev_stop));
+      stage.collide += (double)ms;
+    } else {
+      stage.collide += (double)ms;
+    }
+    HIP_CHECK(hipEventElapsedTime(&ms, g.ev_stop, g.ev_exported));
+    stage.exported += (double)ms;
+  };
   for (int attempt = 0;; ++attempt) {
+    attempts++;
+    /* is every density inside the proven range?  Asked every step, like the tables (a
+     * pass over nx * ny doubles: microseconds), read with the step's counters */
+    HIP_CHECK(hipMemsetAsync(g.d_check + 5, 0, sizeof(unsigned long long), g.stream));
+    if (pad == 0) {
+      HIP_CHECK(neutral::launch_unphysical_values(density, (long long)nx * ny, g.d_check + 5,
+                                                  g.stream));
+    }
+    a.checked = checked ? 1 : 0;
     /* Identical tables (the shipped elastic_scatter.cs / capture.cs are) need one
      * search per energy instead of two, and both searches start from a bucketed
      * index.  The view is cached and its validity checked on the device (see
      * TableView): when the check fails the kernels of this attempt have done
      * nothing, and the step runs again with a fresh view. */
-    refresh_table_view(cs_scatter_table, cs_absorb_table, attempt > 0);
+    refresh_table_view(cs_scatter_table, cs_absorb_table, stale_view, !checked);
     const TableView& v = g.tables;
     same = v.same;
     a.scatter_keys = cs_scatter_table->keys;
@@ -958,23 +1015,33 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
     }
     wait_for_stream();
-    if ((check[4] | check[5]) != 0 && !g.warned_unphysical && !neutral::checked_ranges_build()) {
-      g.warned_unphysical = true;
+    stage = StageMs(); /* (an attempt that was turned down did nothing worth timing) */
+    harvest(true);
+    /* the device's verdict: [6] the cached view of the tables is stale, [7] a fast attempt
+     * met input outside the proven range ([4] tables, [5] densities).  Either way the
+     * kernels of this attempt returned at entry, and it runs again -- with a fresh view,
+     * with the checked instantiation. */
+    stale_view = check[6] != 0;
+    const bool unproven = (check[4] | check[5]) != 0;
+    g.use_checked = unproven; /* (the next step starts from this) */
+    if (unproven && !g.said_checked && !g.quiet) {
+      g.said_checked = true;
       fprintf(stderr,
-              "libneutral_hip: warning: %s%s%s not positive and finite.  This build leaves out the "
-              "range tests of its fast arithmetic, which assume they are (the reference itself "
-              "computes 0/0 there); results in such cells or at such energies may differ from "
-              "the reference's.  Build with -DNEUTRAL_CHECKED_RANGES=1 (INTEGRATION.md) for "
-              "such input.\n",
-              check[5] ? "the density of some cells is" : "", (check[4] && check[5]) ? " and " : "",
-              check[4] ? "some cross-section table entries are" : "");
+              "libneutral_hip: %s%s%s outside [2^-100, 2^100] (a true vacuum of density 0, for "
+              "instance): such steps run the kernels instantiated with IEEE-checked arithmetic, "
+              "which follow the reference's C on infinities and NaNs.\n",
+              check[5] ? "the density of some cells lies" : "", (check[4] && check[5]) ? " and " : "",
+              check[4] ? "some cross-section table entries lie" : "");
+    }
+    if (check[7] != 0) {
+      checked = true;
     }
     /* (several ranks take every decision that leads to another exchange together:
      * the collectives must pair up) */
     if (!(decomposed ? check[0] != 0 : any_rank(check[0] != 0))) {
       break;
     }
-    if (attempt >= 2) {
+    if (attempt >= 3) {
       fprintf(stderr, "libneutral_hip: the cross-section tables keep changing under "
                       "solve_transport_2d.\n");
       exit(EXIT_FAILURE);
@@ -992,6 +1059,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     auto finish_passes = [&]() {
       while (exchange ? any_rank(ctrl[4] != 0) : (ctrl[4] != 0)) {
         neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
+        HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
@@ -1008,6 +1076,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
                                  g.stream));
         wait_for_stream();
+        harvest(false);
         queue_total += ctrl[2];
       }
     };
@@ -1026,6 +1095,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         a.nparticles += arrived;
         neutral::TiledPlan more = {2, -1};
         const int first = passes < 1 ? 1 : passes; /* (pass 0 would start histories over) */
+        HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, first, nullptr,
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
@@ -1034,6 +1104,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
                                  g.stream));
         wait_for_stream();
+        harvest(false);
         queue_total += ctrl[2];
         finish_passes();
       }
@@ -1050,10 +1121,14 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       *nlocal_particles = (int)kept;
       g.rec_count = (int)kept;
       if (pass_export) {
+        HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
         HIP_CHECK(neutral::launch_export_by_slot(g.tiled.rec_in, a.p, shard->keys, (int)kept,
                                                  g.stream));
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         wait_for_stream();
+        float ms_slot = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms_slot, g.ev_stop, g.ev_exported));
+        stage.exported += (double)ms_slot;
       }
       g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
       g.soa_valid = !g.lazy_export;
@@ -1080,19 +1155,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     t.sort_end = ((int)ctrl[8] <= t.sort_end) ? (int)ctrl[8] : t.sort_end;
   }
 
-  float ms = 0.0f;
-  HIP_CHECK(hipEventElapsedTime(&ms, g.ev_start, g.ev_stop));
-  float ms_sort = 0.0f, ms_stream = 0.0f, ms_collide = ms, ms_export = 0.0f;
-  HIP_CHECK(hipEventElapsedTime(&ms_export, g.ev_stop, g.ev_exported));
-  if (tiled) {
-    /* sort_ms: the first sort and the queue build (later sorts sit inside stream_ms) */
-    float ms_collect = 0.0f;
-    HIP_CHECK(hipEventElapsedTime(&ms_sort, g.ev_start, g.ev_sorted));
-    HIP_CHECK(hipEventElapsedTime(&ms_stream, g.ev_sorted, g.ev_streamed));
-    HIP_CHECK(hipEventElapsedTime(&ms_collect, g.ev_streamed, g.ev_collected));
-    HIP_CHECK(hipEventElapsedTime(&ms_collide, g.ev_collected, g.ev_stop));
-    ms_sort += ms_collect;
-  }
+  /* sort_ms: the first sort and the queue builds (later sorts sit inside stream_ms) */
+  const double ms = stage.kernel, ms_sort = stage.sort, ms_stream = stage.stream,
+               ms_collide = stage.collide, ms_export = stage.exported;
 
   if (neutral::comm_nranks() > 1) {
     /* event counters of all ranks (a handful of words: over the host links) */
@@ -1139,6 +1204,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.stream_passes_enqueued = tiled ? passes : 0;
   g.last.tile_cells = tiled ? (1 << g.tiled.tile_shift) : 0;
   g.last.export_ms = (double)ms_export;
+  g.last.checked_arithmetic = checked ? 1 : 0;
+  g.last.attempts = attempts;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */
@@ -1357,6 +1424,16 @@ int neutral_hip_set_variant(int variant) {
 }
 
 void neutral_hip_set_quiet(int quiet) { g.quiet = quiet; }
+
+int neutral_hip_set_arithmetic(int mode) {
+  if (mode != NEUTRAL_HIP_ARITH_AUTO && mode != NEUTRAL_HIP_ARITH_CHECKED) {
+    return 1;
+  }
+  g.arithmetic = mode;
+  g.arithmetic_from_env_done = true; /* an explicit choice overrides the environment */
+  g.use_checked = false;             /* (auto mode starts over: the next step's check decides) */
+  return 0;
+}
 
 void neutral_hip_set_tests_file(const char* path) {
   strncpy(g.tests_file, path, NEUTRAL_MAX_STR_LEN - 1);

@@ -181,8 +181,44 @@ __device__ __forceinline__ int cs_bracket_indexed(const double* __restrict__ key
   return lo;
 }
 
+template <bool kChecked>
 __device__ __forceinline__ double quotient_of_physical(double a, double b); /* below */
 
+/* ---- the arithmetic policy: template <bool kChecked> --------------------------------
+ * Every division, square root and logarithm of the event bodies exists in two forms
+ * that deliver the same bits wherever both are defined:
+ *   kChecked = false  the bare operation sequences (refined reciprocal + three
+ *                     operations, rsq + Goldschmidt, the 42-instruction log) with no
+ *                     range test, exact for operands in the PROVEN RANGE below;
+ *   kChecked = true   IEEE operations on any operand: a range test in front of each
+ *                     fast sequence and the compiler's own division / sqrt / log behind
+ *                     it -- inf, NaN, zero and subnormal operands behave as in the
+ *                     reference's C (omp3/neutral.c:127-146,231,311-317: a true-vacuum
+ *                     cell of density 0 has cell_mfp = 1/0 = inf and runs on infinities).
+ * Both instantiations of every history kernel are in the library.  Which one a step
+ * runs is decided ON THE DEVICE, per step, from the step's own inputs (neutral_kernels.hip:
+ * unphysical_values_kernel, tables_check_kernel): if any density of the mesh or any key
+ * or value of the cross-section tables lies outside [2^-100, 2^100] (zero, negative, inf
+ * and NaN included) the kernels of the fast instantiation return at entry and the host
+ * runs the step with the checked one.
+ *
+ * PROVEN RANGE.  With densities rho, keys and values in [2^-100, 2^100] (and particle
+ * energies inside the keys, without which omp3/neutral.c:498-517 is undefined):
+ *   number density  n = rho * 6.02e25              in [2^-15, 2^186]
+ *   Sigma = n * sigma * 1e-28                       in [2^-208, 2^193]
+ *   cell_mfp = 1 / (Sigma_s + Sigma_a)              in [2^-194, 2^208]
+ *   -log(rn) in {-0} u [2^-54, 45]  =>  mfp_to_collision = -log(rn) / Sigma_s within 2^+-262
+ *   speed = sqrt(2 E eV / m)  with  2 E eV / m in [2^-74, 2^127]
+ *   E'/E and E/E' in [0.96, 1.04];  1 - cos^2 in {+0} u [2^-53, 1]
+ *   interpolation weight (E - k0) / (k1 - k0): differences of doubles of magnitude
+ *     >= 2^-100 are zero or >= 2^-153
+ *   flight distances d: zero, or at least an ulp of a coordinate times a ratio of
+ *     speeds (> 2^-200), and at most the mesh or speed * dt
+ * i.e. every operand and every quotient of a fast sequence is zero or inside
+ * [2^-300, 2^300], where v_div_scale / v_div_fmas / v_div_fixup and the scaling inside
+ * the compiler's sqrt are the identity (tests/test_hip_parity.py checks the sequences
+ * against the compiler's operations on the device over that range). */
+template <bool kChecked>
 __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys,
                                                  const double* __restrict__ values,
                                                  int ind, double energy) {
@@ -192,7 +228,7 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
   const double k1 = k[1];
   const double v0 = v[0];
   const double v1 = v[1];
-  return v0 + quotient_of_physical(energy - k0, k1 - k0) * (v1 - v0);
+  return v0 + quotient_of_physical<kChecked>(energy - k0, k1 - k0) * (v1 - v0);
 }
 
 /* ---- square root without the wrapping ---------------------------------------------
@@ -227,35 +263,32 @@ __device__ __forceinline__ double sqrt_plain_range(double x) {
   return sqrt_known_plain(x);
 }
 
-/* Roots whose argument cannot leave the plain range in any run the reference defines.  A
- * particle's energy lies inside the cross-section tables' keys (1e-2 ... 1e8 eV in the
- * shipped tables; outside them omp3/neutral.c:498-517 reads out of bounds or never
+/* Roots whose argument stays in the plain range on proven-range input (the policy comment
+ * above): a particle's energy lies inside the cross-section tables' keys (1e-2 ... 1e8 eV
+ * in the shipped tables; outside them omp3/neutral.c:498-517 reads out of bounds or never
  * returns), so
  *   - the speed's argument 2 E eV / m (omp3/neutral.c:116,298) is E * 1.9e8,
  *   - the energy ratios E'/E and E/E' of a scatter (:264-265) lie in [(A-1)^2/(A+1)^2, its
  *     inverse] = [0.96, 1.04] whatever E is,
  * and the range test -- a compare, an exec-mask save and restore and a branch per root,
- * in the collision stage where scalar work and branches are what the waves wait on -- can
- * never fire.  NEUTRAL_CHECKED_RANGES=1 brings it back (same bits; A/B in DESIGN.md). */
+ * in the collision stage where scalar work and branches are what the waves wait on -- is
+ * left to the checked instantiation (same bits; A/B in DESIGN.md). */
 /* sqrt(1 - cos^2) of a scattering angle (omp3/neutral.c:266): the argument is +0 -- a
  * head-on cosine of exactly 1 -- or at least an ulp of 1 (2^-53), never in between and
  * never -0; zero is answered by a select instead of a branch.  (A cosine that rounding
  * pushed beyond 1 gives a negative argument and NaN here as in the reference.) */
+template <bool kChecked>
 __device__ __forceinline__ double sqrt_of_sine_squared(double x) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return sqrt_plain_range(x);
-#else
+  if (kChecked) {
+    return sqrt_plain_range(x);
+  }
   const double r = sqrt_known_plain(x);
   return (x == 0.0) ? 0.0 : r;
-#endif
 }
 
+template <bool kChecked>
 __device__ __forceinline__ double sqrt_of_physical(double x) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return sqrt_plain_range(x);
-#else
-  return sqrt_known_plain(x);
-#endif
+  return kChecked ? sqrt_plain_range(x) : sqrt_known_plain(x);
 }
 
 /* ---- log of a sample (omp3/neutral.c:131,295: mfp = -log(rn)/Sigma_s) -----------
@@ -273,6 +306,9 @@ __device__ __forceinline__ double sqrt_of_physical(double x) {
  * depended on its last bit (section 3 of DESIGN.md).  Samples lie in [2^-65, 1];
  * zero, negative, subnormal, infinite and NaN arguments get log()'s answers from a
  * rare branch. */
+__device__ __forceinline__ double refined_reciprocal(double b);                           /* below */
+__device__ __forceinline__ double quotient_by_reciprocal(double a, double b, double r); /* below */
+
 __device__ __forceinline__ double log_core(double x, int k_scaled) {
   double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
   int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
@@ -280,8 +316,10 @@ __device__ __forceinline__ double log_core(double x, int k_scaled) {
   m = low ? m + m : m; /* [sqrt(1/2), sqrt(2)) */
   k = low ? k - 1 : k;
   const double f = m - 1.0; /* exact */
-  /* (f is +0 or 1e-16 ... 0.41 in magnitude, 2 + f is 1.7 ... 2.41: plain operands) */
-  const double s = quotient_of_physical(f, 2.0 + f);
+  /* (f is +0 or 1e-16 ... 0.41 in magnitude, 2 + f is 1.7 ... 2.41: plain operands whatever
+   * the sample was, so both arithmetic policies share this form) */
+  const double denom = 2.0 + f;
+  const double s = quotient_by_reciprocal(f, denom, refined_reciprocal(denom));
   const double z = s * s;
   double r = 2.0 / 21.0;
   r = __builtin_fma(r, z, 2.0 / 19.0);
@@ -322,13 +360,10 @@ __device__ __forceinline__ double log_of_sample(double x) {
 }
 
 /* a sample as generate_random_numbers makes it: u64 * 2^-64 + 2^-65, in [2^-65, 1] -- the
- * special cases above cannot occur (same switch as sqrt_of_physical) */
+ * special cases above cannot occur (same policy switch as sqrt_of_physical) */
+template <bool kChecked>
 __device__ __forceinline__ double log_of_drawn_sample(double x) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return log_of_sample(x);
-#else
-  return log_core(x, 0);
-#endif
+  return kChecked ? log_of_sample(x) : log_core(x, 0);
 }
 
 /* ---- quotients by a denominator that many numerators share --------------------
@@ -365,20 +400,20 @@ __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, dou
   return __builtin_fma(rem, r, q0);
 }
 
-/* a / b where neither operand nor the quotient can leave the plain range in a run the
- * reference defines, and a may be +0 (not -0): the interpolation weight (E - k0)/(k1 - k0)
+/* a / b where neither operand nor the quotient leaves the plain range on proven-range
+ * input, and a may be +0 (not -0): the interpolation weight (E - k0)/(k1 - k0)
  * of a table lookup (omp3/neutral.c:514: keys are positive and increasing, E >= k0, a
  * difference of doubles of magnitude 1e-2 ... 1e8 is zero or at least 1e-18), the mean free
  * path 1/(Sigma_s + Sigma_a) (:135) and the flight time d/speed (:297).  Eight operations
  * instead of the wrapped division's thirteen, same bits (the refined reciprocal and the
  * three operations of quotient_by_reciprocal: tested against the compiler's division,
- * tests/test_hip_parity.py); NEUTRAL_CHECKED_RANGES=1 divides. */
+ * tests/test_hip_parity.py); the checked policy divides. */
+template <bool kChecked>
 __device__ __forceinline__ double quotient_of_physical(double a, double b) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return a / b;
-#else
+  if (kChecked) {
+    return a / b;
+  }
   return quotient_by_reciprocal(a, b, refined_reciprocal(b));
-#endif
 }
 
 /* a / b for a compile-time constant b: with y = RN(1/b) (rounded correctly by the
@@ -395,16 +430,15 @@ __device__ __forceinline__ double quotient_by_constant(double a, double b, doubl
   asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
   return a / b;
 }
-/* the same for a numerator that cannot leave the plain range in a run the reference
- * defines (see sqrt_of_physical): an energy of 1e-2 ... 1e8 eV times 2 eV_TO_J (3.2e-19),
- * or times A^2 + 2 A mu + 1 (9 801 ... 10 201) -- no range test, no branch */
-template <typename Tag>
+/* the same for a numerator that stays in the plain range on proven-range input (see
+ * sqrt_of_physical): an energy of 1e-2 ... 1e8 eV times 2 eV_TO_J (3.2e-19), or times
+ * A^2 + 2 A mu + 1 (9 801 ... 10 201) -- no range test, no branch */
+template <typename Tag, bool kChecked>
 __device__ __forceinline__ double quotient_of_physical_by_constant(double a, double b, double y) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return quotient_by_constant<Tag>(a, b, y);
-#else
+  if (kChecked) {
+    return quotient_by_constant<Tag>(a, b, y);
+  }
   return quotient_by_reciprocal(a, b, y);
-#endif
 }
 struct ByParticleMass {};
 struct ByMassNoPlusOneSquared {};
@@ -412,15 +446,21 @@ constexpr double kMassNoPlusOneSquared = (kMassNo + 1.0) * (kMassNo + 1.0);
 
 /* ---- geometry (omp3/neutral.c:423-471) ------------------------------------- */
 
-__device__ __forceinline__ void calc_distance_to_facet(
-    double x, double y, double omega_x, double omega_y, double speed, double u_x_inv,
-    double u_y_inv, double ex_lo, double ex_hi, double ey_lo, double ey_hi,
-    double& distance_to_facet, int& x_facet) {
-  /* u_x_inv = 1/(omega_x*speed), u_y_inv = 1/(omega_y*speed): omp3/neutral.c:435-436 */
+/* The coordinate a history aims at on one axis (omp3/neutral.c:438-447): the cell's upper
+ * edge when it moves up the axis, and -- the bound being open on the left/bottom --
+ * slightly past the lower edge when it moves down. */
+__device__ __forceinline__ double facet_target(double omega, double e_lo, double e_hi) {
+  return (omega >= 0.0) ? e_hi : (e_lo - kOpenBoundCorrection);
+}
 
-  /* the bound is open on the left/bottom: aim slightly past the edge */
-  const double ax = (omega_x >= 0.0) ? (ex_hi - x) : ((ex_lo - kOpenBoundCorrection) - x);
-  const double ay = (omega_y >= 0.0) ? (ey_hi - y) : ((ey_lo - kOpenBoundCorrection) - y);
+/* distance to the facet from the two targets (the rest of omp3/neutral.c:449-470) */
+__device__ __forceinline__ void calc_distance_to_targets(double x, double y, double speed,
+                                                         double u_x_inv, double u_y_inv,
+                                                         double target_x, double target_y,
+                                                         double& distance_to_facet, int& x_facet) {
+  /* u_x_inv = 1/(omega_x*speed), u_y_inv = 1/(omega_y*speed): omp3/neutral.c:435-436 */
+  const double ax = target_x - x;
+  const double ay = target_y - y;
   const double dt_x = ax * u_x_inv;
   const double dt_y = ay * u_y_inv;
   x_facet = (dt_x < dt_y) ? 1 : 0;
@@ -428,10 +468,26 @@ __device__ __forceinline__ void calc_distance_to_facet(
   distance_to_facet = x_facet ? (ax * speed) * u_x_inv : (ay * speed) * u_y_inv;
 }
 
+__device__ __forceinline__ void calc_distance_to_facet(
+    double x, double y, double omega_x, double omega_y, double speed, double u_x_inv,
+    double u_y_inv, double ex_lo, double ex_hi, double ey_lo, double ey_hi,
+    double& distance_to_facet, int& x_facet) {
+  calc_distance_to_targets(x, y, speed, u_x_inv, u_y_inv, facet_target(omega_x, ex_lo, ex_hi),
+                           facet_target(omega_y, ey_lo, ey_hi), distance_to_facet, x_facet);
+}
+
+template <bool kChecked>
 __device__ __forceinline__ double speed_of(double energy) {
   /* omp3/neutral.c:117,297 */
-  return sqrt_of_physical(quotient_of_physical_by_constant<ByParticleMass>(
+  return sqrt_of_physical<kChecked>(quotient_of_physical_by_constant<ByParticleMass, kChecked>(
       2.0 * energy * kEvToJ, kParticleMass, 1.0 / kParticleMass));
+}
+
+/* inside [2^-100, 2^100]: what the fast arithmetic policy is proven on (the comment at the
+ * top of the policy section); zero, negative, infinite and NaN values are outside */
+__device__ __forceinline__ bool in_proven_range(double v) {
+  const unsigned hi = (unsigned)__double2hiint(v); /* sign bit set: fails the test below */
+  return (hi - (923u << 20)) < (200u << 20);
 }
 
 }  // namespace neutral

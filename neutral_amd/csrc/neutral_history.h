@@ -55,6 +55,12 @@ struct History {
    * for the two quotients of a facet crossing, and whether each may be used */
   double r_speed, r_cell_mfp;
   int plain_div; /* bit 0: speed, bit 1: cell_mfp inside the plain division range */
+  /* stream kernel only: the two coordinates the history aims at (facet_target of its cell's
+   * edges and its direction).  A streaming history keeps its direction from facet to facet,
+   * so a crossing replaces the edges of the axis it crossed -- loaded together with the
+   * new cell's density, before the arithmetic of the crossing -- instead of reading all
+   * four edges again at the next loop head (omp3/neutral.c:438-447 reads them per event) */
+  double target_x, target_y;
   unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
   unsigned nevents; /* events of this history so far: watchdog only */
@@ -191,7 +197,7 @@ __device__ __forceinline__ int bracket_of(const double* keys, int n, IndexPtr in
 }
 
 /* both microscopic cross sections for one energy */
-template <bool kSameTables, typename IndexPtr>
+template <bool kSameTables, bool kChecked, typename IndexPtr>
 __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<IndexPtr>& ix,
                                           double energy, double& micro_scatter,
                                           double& micro_absorb) {
@@ -205,13 +211,13 @@ __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<Ind
 #endif
   const int is = bracket_of(a.scatter_keys, a.scatter_n, ix.scatter_index, a.scatter_index_n,
                             a.index_shift, a.scatter_index_base, energy);
-  micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
+  micro_scatter = cs_interpolate<kChecked>(a.scatter_keys, a.scatter_values, is, energy);
   if (kSameTables) {
     micro_absorb = micro_scatter;
   } else {
     const int ia = bracket_of(a.absorb_keys, a.absorb_n, ix.absorb_index, a.absorb_index_n,
                               a.index_shift, a.absorb_index_base, energy);
-    micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
+    micro_absorb = cs_interpolate<kChecked>(a.absorb_keys, a.absorb_values, ia, energy);
   }
 }
 
@@ -285,70 +291,71 @@ __device__ __forceinline__ CsSearch lookup_cs_begin(const SolveArgs& a,
   return s;
 }
 
-template <bool kSameTables>
+template <bool kSameTables, bool kChecked>
 __device__ __forceinline__ void lookup_cs_finish(const SolveArgs& a, const CsSearch& s,
                                                  double energy, double& micro_scatter,
                                                  double& micro_absorb) {
   const int is = bracket_finish(a.scatter_keys, s.scatter, energy);
-  micro_scatter = cs_interpolate(a.scatter_keys, a.scatter_values, is, energy);
+  micro_scatter = cs_interpolate<kChecked>(a.scatter_keys, a.scatter_values, is, energy);
   if (kSameTables) {
     micro_absorb = micro_scatter;
   } else {
     const int ia = bracket_finish(a.absorb_keys, s.absorb, energy);
-    micro_absorb = cs_interpolate(a.absorb_keys, a.absorb_values, ia, energy);
+    micro_absorb = cs_interpolate<kChecked>(a.absorb_keys, a.absorb_values, ia, energy);
   }
 }
 
 /* macroscopic cross sections from number_density and the microscopic ones
  * (omp3/neutral.c:114-116, :290-291, :376-377) and the loop head's :135 */
+template <bool kChecked>
 __device__ __forceinline__ void macroscopic_from_micro(History& h) {
   h.macro_s = h.number_density * h.micro_s * kBarns;
   h.macro_a = h.number_density * h.micro_a * kBarns;
-  h.cell_mfp = quotient_of_physical(1.0, h.macro_s + h.macro_a);
+  h.cell_mfp = quotient_of_physical<kChecked>(1.0, h.macro_s + h.macro_a);
 }
 
+template <bool kChecked>
 __device__ __forceinline__ void macroscopic_from_density(History& h) {
   /* omp3/neutral.c:112-113, :289, :375.  A collision re-evaluates this quotient
    * from an unchanged density (:289): same operands, same bits, so collide()
    * keeps the value and calls macroscopic_from_micro() alone. */
   h.number_density = (h.local_density * kAvogadros / kMolarMass);
-  macroscopic_from_micro(h);
+  macroscopic_from_micro<kChecked>(h);
 }
 
 /* x / (x + x) for two bit-identical operands, as p_absorb (omp3/neutral.c:224)
  * and the absorbed fraction (:481-482) become when both cs tables hold the same
  * data: x + x is exact and the quotient is exactly one half unless x is zero,
  * infinite or NaN, or the sum overflows -- those go through the division. */
+template <bool kChecked>
 __device__ __forceinline__ double half_or_quotient(double x, double sum) {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  if (__builtin_expect(sum != 0.0 && fabs(sum) < __builtin_huge_val(), 1)) {
-    return 0.5;
+  if (kChecked) {
+    if (__builtin_expect(sum != 0.0 && fabs(sum) < __builtin_huge_val(), 1)) {
+      return 0.5;
+    }
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    return x / sum;
   }
-  asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
-  return x / sum;
-#else
-  /* One half, without the test (neutral_device.h: sqrt_of_physical has the reasoning for
-   * this switch).  A cross section that is zero, infinite or NaN cannot reach the two
-   * callers in a run with a meaningful result: a collision needs a finite distance to it,
-   * i.e. a finite non-zero macroscopic cross section (the comparisons of
-   * omp3/neutral.c:160-163 are false for NaN), and a zero microscopic one makes the
-   * reference's own heating 0/0 and its tally NaN. */
+  /* One half, without the test: on proven-range input (neutral_device.h: the arithmetic
+   * policy) a cross section is neither zero nor infinite nor NaN and the sum cannot
+   * overflow. */
   return 0.5;
-#endif
 }
 
+template <bool kChecked>
 __device__ __forceinline__ void refresh_speed_reciprocal(History& h) {
   h.r_speed = refined_reciprocal(h.speed);
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  h.plain_div = (h.plain_div & ~1) | (in_plain_division_range(h.speed) ? 1 : 0);
-#endif
+  if (kChecked) {
+    h.plain_div = (h.plain_div & ~1) | (in_plain_division_range(h.speed) ? 1 : 0);
+  }
 }
 
+template <bool kChecked>
 __device__ __forceinline__ void refresh_mfp_reciprocal(History& h) {
   h.r_cell_mfp = refined_reciprocal(h.cell_mfp);
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  h.plain_div = (h.plain_div & ~2) | (in_plain_division_range(h.cell_mfp) ? 2 : 0);
-#endif
+  if (kChecked) {
+    h.plain_div = (h.plain_div & ~2) | (in_plain_division_range(h.cell_mfp) ? 2 : 0);
+  }
 }
 
 /* omp3/neutral.c:435-436 */
@@ -359,13 +366,13 @@ __device__ __forceinline__ void refresh_direction(History& h) {
 
 /* the energy- and table-dependent factors of calculate_energy_deposition
  * (omp3/neutral.c:481-494); deposit() below finishes the product */
-template <bool kSameTables>
+template <bool kSameTables, bool kChecked>
 __device__ __forceinline__ void refresh_deposition_terms(History& h) {
   const double microscopic_cs_total = h.micro_s + h.micro_a;
   constexpr double average_exit_energy_absorb = 0.0;
   /* identical tables: micro_s and micro_a are the same bits (lookup_cs) */
   const double absorbed_fraction = kSameTables
-                                       ? half_or_quotient(h.micro_a, microscopic_cs_total)
+                                       ? half_or_quotient<kChecked>(h.micro_a, microscopic_cs_total)
                                        : (h.micro_a / microscopic_cs_total);
   const double absorption_heating = absorbed_fraction * average_exit_energy_absorb;
   const double average_exit_energy_scatter =
@@ -494,14 +501,14 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
 }
 
 /* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */
-template <bool kSameTables, typename IndexPtr>
+template <bool kSameTables, bool kChecked, typename IndexPtr>
 __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
                                          const CsLookup<IndexPtr>& ix) {
   h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
                               (h.cellx - a.x_off + a.pad)];
-  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
-  macroscopic_from_density(h);
-  h.speed = speed_of(h.energy);
+  lookup_cs<kSameTables, kChecked>(a, ix, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_density<kChecked>(h);
+  h.speed = speed_of<kChecked>(h.energy);
   h.energy_deposition = 0.0;
   h.track_length = 0.0;
   h.counter = 0;
@@ -509,9 +516,9 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
   h.dt_to_census = a.dt;
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  h.mfp_to_collision = -log_of_drawn_sample(rn0) / h.macro_s;
+  h.mfp_to_collision = -log_of_drawn_sample<kChecked>(rn0) / h.macro_s;
   refresh_direction(h);
-  refresh_deposition_terms<kSameTables>(h);
+  refresh_deposition_terms<kSameTables, kChecked>(h);
 }
 
 /* Re-derives the locals of a history that another kernel suspended at a loop
@@ -521,21 +528,21 @@ __device__ __forceinline__ void prologue(History& h, const SolveArgs& a,
  * travels in the record's last word (one draw, the prologue's, for a history that
  * has only streamed) and nothing is pending in the deposition accumulator (every
  * facet flushes it, omp3/neutral.c:325-327). */
-template <bool kSameTables, typename IndexPtr>
+template <bool kSameTables, bool kChecked, typename IndexPtr>
 __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
                                        const CsLookup<IndexPtr>& ix) {
   /* h.dt_to_census and h.mfp_to_collision come from the record (load_record) */
   h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
                               (h.cellx - a.x_off + a.pad)];
-  lookup_cs<kSameTables>(a, ix, h.energy, h.micro_s, h.micro_a);
-  macroscopic_from_density(h);
-  h.speed = speed_of(h.energy);
+  lookup_cs<kSameTables, kChecked>(a, ix, h.energy, h.micro_s, h.micro_a);
+  macroscopic_from_density<kChecked>(h);
+  h.speed = speed_of<kChecked>(h.energy);
   h.energy_deposition = 0.0;
   h.track_length = 0.0;
   /* h.counter comes from the record as well: 1 for a history that has only streamed */
   h.nevents = 0;
   refresh_direction(h);
-  refresh_deposition_terms<kSameTables>(h);
+  refresh_deposition_terms<kSameTables, kChecked>(h);
 }
 
 /* the four mesh edges around a cell (omp3/neutral.c:438-447 reads them per event) */
@@ -591,6 +598,30 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const Cel
   }
 }
 
+/* loop head for a history that carries its targets (stream kernel): no edge loads here */
+__device__ __forceinline__ void decide_carried(History& h) {
+  const bool running = (h.dt_to_census > 0.0);
+  double distance_to_facet;
+  calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv, h.target_x, h.target_y,
+                           distance_to_facet, h.x_facet);
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  const bool collides = (distance_to_collision < distance_to_facet) &
+                        (distance_to_collision < distance_to_census);
+  const bool crosses = (distance_to_facet < distance_to_census);
+  h.ev = collides ? kEvCollision : (crosses ? kEvFacet : kEvCensus);
+  h.distance = collides ? distance_to_collision
+                        : (crosses ? distance_to_facet : distance_to_census);
+  h.ev = running ? h.ev : (int)kEvEnd;
+}
+
+/* the targets of the history's cell and direction, from the edge arrays */
+__device__ __forceinline__ void load_targets(History& h, const SolveArgs& a) {
+  const CellEdges e = load_edges(a, h.cellx, h.celly);
+  h.target_x = facet_target(h.omega_x, e.x_lo, e.x_hi);
+  h.target_y = facet_target(h.omega_y, e.y_lo, e.y_hi);
+}
+
 template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 #if defined(NEUTRAL_EXP_COMPUTED_EDGES)
@@ -605,7 +636,7 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables, typename IndexPtr, typename Tally>
+template <bool kSameTables, bool kChecked, typename IndexPtr, typename Tally>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
                                         const CsLookup<IndexPtr>& ix, const Tally& tally) {
   const double distance_to_collision = h.distance;
@@ -617,7 +648,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   h.y += distance_to_collision * h.omega_y;
 
   /* identical tables: macro_s and macro_a are the same bits (macroscopic_from_micro) */
-  const double p_absorb = kSameTables ? half_or_quotient(h.macro_a, h.macro_s + h.macro_a)
+  const double p_absorb = kSameTables ? half_or_quotient<kChecked>(h.macro_a, h.macro_s + h.macro_a)
                                       : h.macro_a / (h.macro_s + h.macro_a);
   double rc0, rc1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
@@ -642,16 +673,18 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
    * table search for it (:281-286) starts here, and its first probe is in flight
    * while the scattered lanes work out their direction (:254-272). */
   const double mu_cm = 1.0 - 2.0 * rc1;
-  const double e_scattered = quotient_of_physical_by_constant<ByMassNoPlusOneSquared>(
+  const double e_scattered = quotient_of_physical_by_constant<ByMassNoPlusOneSquared, kChecked>(
       h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared,
       1.0 / kMassNoPlusOneSquared);
   const double e_new = absorbed ? h.energy : e_scattered;
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {
     const double cos_theta =
-        0.5 * ((kMassNo + 1.0) * sqrt_of_physical(quotient_of_physical(e_new, h.energy)) -
-               (kMassNo - 1.0) * sqrt_of_physical(quotient_of_physical(h.energy, e_new)));
-    const double sin_theta = sqrt_of_sine_squared(1.0 - cos_theta * cos_theta);
+        0.5 * ((kMassNo + 1.0) *
+                   sqrt_of_physical<kChecked>(quotient_of_physical<kChecked>(e_new, h.energy)) -
+               (kMassNo - 1.0) *
+                   sqrt_of_physical<kChecked>(quotient_of_physical<kChecked>(h.energy, e_new)));
+    const double sin_theta = sqrt_of_sine_squared<kChecked>(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
     h.omega_x = omega_x_new;
@@ -663,14 +696,13 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
    * and its logarithm are worked out while the search is still in flight */
   double rn0, rn1;
   generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  const double minus_log_rn0 = -log_of_drawn_sample(rn0);
+  const double minus_log_rn0 = -log_of_drawn_sample<kChecked>(rn0);
 
-  lookup_cs_finish<kSameTables>(a, search, h.energy, h.micro_s, h.micro_a);
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
-  h.mfp_to_collision = minus_log_rn0 / h.macro_s; /* (-0.0 for a sample of exactly 1) */
-#else
-  if (kSameTables) {
+  lookup_cs_finish<kSameTables, kChecked>(a, search, h.energy, h.micro_s, h.micro_a);
+  if (kChecked) {
+    macroscopic_from_micro<true>(h); /* the density, hence number_density, has not changed (:289) */
+    h.mfp_to_collision = minus_log_rn0 / h.macro_s; /* (-0.0 for a sample of exactly 1) */
+  } else if (kSameTables) {
     /* Identical tables: Sigma_a is Sigma_s bit for bit, so the mean free path 1/(Sigma_s +
      * Sigma_a) (:135) is exactly half of 1/Sigma_s -- x + x and the halving are exact --
      * and it shares the refined reciprocal of Sigma_s with -log(rn)/Sigma_s (:295): two
@@ -685,14 +717,13 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
     const double q = quotient_by_reciprocal(minus_log_rn0, h.macro_s, r);
     h.mfp_to_collision = (minus_log_rn0 == 0.0) ? minus_log_rn0 : q;
   } else {
-    macroscopic_from_micro(h); /* the density, hence number_density, has not changed (:289) */
+    macroscopic_from_micro<false>(h); /* the density, hence number_density, has not changed (:289) */
     h.mfp_to_collision = minus_log_rn0 / h.macro_s; /* (-0.0 for a sample of exactly 1) */
   }
-#endif
-  h.dt_to_census -= quotient_of_physical(distance_to_collision, h.speed);
-  h.speed = speed_of(h.energy);
+  h.dt_to_census -= quotient_of_physical<kChecked>(distance_to_collision, h.speed);
+  h.speed = speed_of<kChecked>(h.energy);
   refresh_direction(h);
-  refresh_deposition_terms<kSameTables>(h);
+  refresh_deposition_terms<kSameTables, kChecked>(h);
   return false;
 }
 
@@ -708,7 +739,11 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
 /* kDomain: may the neighbour cell belong to another rank (spatial decomposition)?
  * 0 never, 1 always, 2 ask a.decomposed (wave-uniform; free in the collision stage,
  * but six percent of the stream kernel, which therefore compiles both answers). */
-template <bool kCachedReciprocals = false, int kDomain = 2, typename Tally>
+/* kCarryTargets: the history keeps target_x / target_y (stream kernel): the edges of the
+ * cell it enters are loaded here, next to the density, and the reflection -- rare -- sits
+ * behind one wave-uniform branch instead of eight selects per facet. */
+template <bool kChecked, bool kCachedReciprocals = false, int kDomain = 2, bool kCarryTargets = false,
+          typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
   /* step to the neighbour cell, or reflect at the outer boundary (:333-369), as
    * selects: the branch ladder of the reference costs ~35 scalar instructions of
@@ -739,31 +774,46 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   }
   const double new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
 #endif
+  /* the edges of the cell the history will be in, on both axes (two 16-byte loads issued
+   * here, consumed after the arithmetic below; a reflection leaves the cell, hence them,
+   * unchanged) */
+  CellEdges ne{0.0, 0.0, 0.0, 0.0};
+  if (kCarryTargets) {
+    int ex = ncellx - a.x_off + a.pad;
+    int ey = ncelly - a.y_off + a.pad;
+    if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
+      ex = (ex < 0) ? 0 : ((ex >= a.nx + 2 * a.pad) ? a.nx + 2 * a.pad - 1 : ex);
+      ey = (ey < 0) ? 0 : ((ey >= a.ny + 2 * a.pad) ? a.ny + 2 * a.pad - 1 : ey);
+    }
+    const double* px = mesh_element(a.edgex, ex);
+    const double* py = mesh_element(a.edgey, ey);
+    ne = CellEdges{px[0], px[1], py[0], py[1]};
+  }
 
   const double distance_to_facet = h.distance;
   if (kCachedReciprocals) {
     /* both quotients of :311-312 through the kept reciprocals */
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-    if (__builtin_expect((h.plain_div == 3) & in_plain_division_range(distance_to_facet), 1)) {
+    if (kChecked) {
+      if (__builtin_expect((h.plain_div == 3) & in_plain_division_range(distance_to_facet), 1)) {
+        h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
+        h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
+      } else {
+        asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+        h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
+        h.dt_to_census -= (distance_to_facet / h.speed);
+      }
+    } else {
+      /* No range test on proven-range input (neutral_device.h: the arithmetic policy).  A
+       * distance to a facet is +0 (the particle sits on the edge it is heading for) or at
+       * least an ulp of a coordinate times a speed/speed ratio, and at most the mesh; the
+       * shipped decks have speeds of 1e3 ... 1e8 and mean free paths of 1e-6 ... 1e29
+       * (densities of 1e-30 ... 1e4; a true vacuum of density 0 runs checked). */
       h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
       h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
-    } else {
-      asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
-      h.mfp_to_collision -= (distance_to_facet / h.cell_mfp);
-      h.dt_to_census -= (distance_to_facet / h.speed);
     }
-#else
-    /* No range test (neutral_device.h: sqrt_of_physical has the reasoning).  A distance to
-     * a facet is +0 (the particle sits on the edge it is heading for) or at least an ulp
-     * of a coordinate times a speed/speed ratio, i.e. > 1e-20, and at most the mesh; a
-     * speed is 1e3 ... 1e8 and a mean free path 1e-6 ... 1e29 (densities of 1e-30 ... 1e4:
-     * the reference's vacuum is 1e-30, because zero makes its own quotients 0/0). */
-    h.mfp_to_collision -= quotient_by_reciprocal(distance_to_facet, h.cell_mfp, h.r_cell_mfp);
-    h.dt_to_census -= quotient_by_reciprocal(distance_to_facet, h.speed, h.r_speed);
-#endif
   } else {
-    h.mfp_to_collision -= quotient_of_physical(distance_to_facet, h.cell_mfp);
-    h.dt_to_census -= quotient_of_physical(distance_to_facet, h.speed);
+    h.mfp_to_collision -= quotient_of_physical<kChecked>(distance_to_facet, h.cell_mfp);
+    h.dt_to_census -= quotient_of_physical<kChecked>(distance_to_facet, h.speed);
   }
   h.energy_deposition += deposit(h, distance_to_facet);
   tally(a, h.cellx, h.celly, h.energy_deposition);
@@ -780,12 +830,25 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
    * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
   const bool flip_x = reflect & xf;
   const bool flip_y = reflect & !xf;
-  h.omega_x = flip_x ? -h.omega_x : h.omega_x;
-  h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
-  h.omega_y = flip_y ? -h.omega_y : h.omega_y;
-  h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
+  if (kCarryTargets) {
+    if (__ballot(reflect) != 0) { /* wave-uniform: most trips of the facet loop skip it */
+      h.omega_x = flip_x ? -h.omega_x : h.omega_x;
+      h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
+      h.omega_y = flip_y ? -h.omega_y : h.omega_y;
+      h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
+    }
+  } else {
+    h.omega_x = flip_x ? -h.omega_x : h.omega_x;
+    h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
+    h.omega_y = flip_y ? -h.omega_y : h.omega_y;
+    h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
+  }
   h.cellx = ncellx;
   h.celly = ncelly;
+  if (kCarryTargets) {
+    h.target_x = facet_target(h.omega_x, ne.x_lo, ne.x_hi);
+    h.target_y = facet_target(h.omega_y, ne.y_lo, ne.y_hi);
+  }
 
   /* pin the two quotients above the wait for the density: left alone, the compiler
    * sinks both divides below the branch that consumes the load */
@@ -793,20 +856,20 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
-    macroscopic_from_density(h);
+    macroscopic_from_density<kChecked>(h);
     if (kCachedReciprocals) {
-      refresh_mfp_reciprocal(h);
+      refresh_mfp_reciprocal<kChecked>(h);
     }
   }
 }
 
 /* census_event, omp3/neutral.c:383-405 */
-template <typename Tally>
+template <bool kChecked, typename Tally>
 __device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tally& tally) {
   const double distance_to_census = h.distance;
   h.x += distance_to_census * h.omega_x;
   h.y += distance_to_census * h.omega_y;
-  h.mfp_to_collision -= quotient_of_physical(distance_to_census, h.cell_mfp);
+  h.mfp_to_collision -= quotient_of_physical<kChecked>(distance_to_census, h.cell_mfp);
   h.energy_deposition += deposit(h, distance_to_census);
   tally(a, h.cellx, h.celly, h.energy_deposition);
   if (Tally::kFlux) {

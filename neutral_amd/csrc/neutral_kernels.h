@@ -107,6 +107,9 @@ struct SolveArgs {
   const double* absorb_values;
   int absorb_n;
   int same_tables; /* both tables have identical contents: search once */
+  int checked;     /* arithmetic policy of the event bodies (neutral_device.h): 0 the fast
+                      sequences, proven on densities and table entries in [2^-100, 2^100];
+                      1 IEEE operations with range tests, any input the reference accepts */
   /* exponent-bucketed indexes over the key arrays (start == null: none) */
   const unsigned short* scatter_index;
   int scatter_index_n;
@@ -243,17 +246,18 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
  * out[0] = 1 unless hash(scatter keys) == expect_hash_s, hash(absorb keys) ==
  * expect_hash_a and (tables element-wise identical) == expect_same; out[1], out[2] =
  * the two hashes, out[3] = the identity flag (all four words are written). */
-/* out[0] |= 1 when a value is not positive, finite and inside [2^-300, 2^300) */
+/* out[0] |= 1 when a value lies outside [2^-100, 2^100] (zero, negative, inf, NaN too) */
 hipError_t launch_unphysical_values(const double* v, long long n, unsigned long long* out,
                                     hipStream_t stream);
-/* was the library built with NEUTRAL_CHECKED_RANGES (range tests around every fast path)? */
-bool checked_ranges_build();
-/* out: 8 words -- [0] verdict, [1..3] hashes and identity, [4] |= 1 when a key or value is
- * not physical (sticky: the caller clears it) */
+/* out: 8 words -- [0] the abort flag of the step's history kernels = [6] | [7]; [1..3]
+ * hashes and identity; [4] a key or value lies outside [2^-100, 2^100]; [5] (written by
+ * launch_unphysical_values before this kernel) a density does; [6] the expected hashes /
+ * identity do not match; [7] fast_arithmetic was launched and [4] or [5] is set */
 hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
                                const double* va, int na, unsigned long long expect_hash_s,
                                unsigned long long expect_hash_a, int expect_same,
-                               unsigned long long* out4, hipStream_t stream);
+                               int fast_arithmetic, unsigned long long* out4,
+                               hipStream_t stream);
 
 
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */

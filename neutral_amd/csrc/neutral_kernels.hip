@@ -178,7 +178,7 @@ hipError_t launch_inject_filtered(const InjectArgs& a, unsigned* keys, unsigned*
 
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
-template <bool kSameTables, bool kFlux>
+template <bool kSameTables, bool kFlux, bool kChecked>
 __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(SolveArgs a) {
   const int pid = blockIdx.x * kBlock + threadIdx.x;
 
@@ -196,21 +196,21 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
     const GlobalTallyT<kFlux> tally;
     History h;
     load_particle(h, a, pid);
-    prologue<kSameTables>(h, a, ix);
+    prologue<kSameTables, kChecked>(h, a, ix);
     for (;;) { /* omp3/neutral.c:134-197 */
       decide(h, a);
       if (h.ev == kEvCollision) {
         ncollisions++;
-        if (collide<kSameTables>(h, a, ix, tally)) {
+        if (collide<kSameTables, kChecked>(h, a, ix, tally)) {
           break;
         }
       } else if (h.ev == kEvFacet) {
         nfacets++;
-        cross_facet(h, a, tally);
+        cross_facet<kChecked>(h, a, tally);
       } else {
         if (h.ev == kEvCensus) {
           ncensus = 1;
-          census(h, a, tally);
+          census<kChecked>(h, a, tally);
         }
         break;
       }
@@ -363,8 +363,8 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * colliders mixed (parked lanes make occupancy matter: 4 waves/SIMD, small
  * spill); kQueue = true: the collision stage of the tiled pipeline, histories
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
-template <bool kSameTables, bool kQueue, bool kFlux>
-__global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux) ? NEUTRAL_K2_QUEUE_WAVES : 3)
+template <bool kSameTables, bool kQueue, bool kFlux, bool kChecked>
+__global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux && !kChecked) ? NEUTRAL_K2_QUEUE_WAVES : 3)
                                              : NEUTRAL_K2_WAVES)
 void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
@@ -538,7 +538,7 @@ void history_regroup_kernel(SolveArgs a) {
         const unsigned e = *ring_slot(ring_head + rank);
         pid = (int)(e & ~kRequeued);
         load_record(h, c, c.rec[pid]);
-        resume<kSameTables>(h, c, ix); /* counted as processed by the suspender */
+        resume<kSameTables, kChecked>(h, c, ix); /* counted as processed by the suspender */
         if (e & kRequeued) {
           const SuspendExtra x = c.susp[pid];
           h.energy_deposition = x.energy_deposition;
@@ -583,13 +583,13 @@ void history_regroup_kernel(SolveArgs a) {
             const SolveArgs c = NEUTRAL_COLD_ARGS(a);
             pid = (int)c.queue[mine];
             load_record(h, c, c.rec[pid]);
-            resume<kSameTables>(h, c, ix); /* counted as processed by the suspender */
+            resume<kSameTables, kChecked>(h, c, ix); /* counted as processed by the suspender */
           }
         } else if (take && !a.p.dead[mine]) { /* omp3/neutral.c:91-93 */
           pid = mine;
           nprocessed++;
           load_particle(h, a, pid);
-          prologue<kSameTables>(h, a, ix);
+          prologue<kSameTables, kChecked>(h, a, ix);
         } else {
           take = false;
         }
@@ -614,7 +614,7 @@ void history_regroup_kernel(SolveArgs a) {
           if (!kQueue) {
             ncollisions++;
           }
-          if (collide<kSameTables>(h, a, ix, tally)) {
+          if (collide<kSameTables, kChecked>(h, a, ix, tally)) {
             put_back<kQueue>(h, NEUTRAL_COLD_ARGS(a), pid);
             want = kWantRefill;
           } else {
@@ -675,7 +675,7 @@ void history_regroup_kernel(SolveArgs a) {
         const SolveArgs c = NEUTRAL_COLD_ARGS(a);
         if (h.ev == kEvFacet) {
           nfacets++;
-          cross_facet(h, c, tally);
+          cross_facet<kChecked>(h, c, tally);
           if (kQueue && c.decomposed && outside_domain(h, c)) {
             /* into another rank's cells: the history waits to be sent (its RNG counter
              * travels in the record) */
@@ -690,7 +690,7 @@ void history_regroup_kernel(SolveArgs a) {
         } else {
           if (h.ev == kEvCensus) {
             ncensus++;
-            census(h, c, tally);
+            census<kChecked>(h, c, tally);
           }
           put_back<kQueue>(h, c, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
@@ -751,14 +751,13 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
   return x;
 }
 
-/* positive, finite, and far enough from the ends of the exponent range that the event
- * bodies' unwrapped arithmetic is exact on it (neutral_device.h: sqrt_of_physical) */
-__device__ __forceinline__ bool is_physical(double v) {
-  return (v > 0.0) & in_plain_division_range(v);
-}
+/* inside the range the fast arithmetic policy is proven on: [2^-100, 2^100], which also
+ * excludes zero, negative, infinite and NaN values (neutral_device.h: the arithmetic policy) */
+__device__ __forceinline__ bool is_physical(double v) { return in_proven_range(v); }
 
-/* out[0] = 1 if any of n values is not (the default build's fast arithmetic assumes they
- * all are; the host says so once, loudly, and names the checked build) */
+/* out[0] |= 1 if any of n values is not: the step's kernels of the fast instantiation
+ * then return at entry (tables_check_kernel folds this word into the abort flag) and the
+ * host runs the step with the checked one */
 __global__ __launch_bounds__(1024) void unphysical_values_kernel(const double* v, long long n,
                                                                  unsigned long long* out) {
   const long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
@@ -777,20 +776,13 @@ hipError_t launch_unphysical_values(const double* v, long long n, unsigned long 
   return hipGetLastError();
 }
 
-bool checked_ranges_build() {
-#if defined(NEUTRAL_CHECKED_RANGES) && NEUTRAL_CHECKED_RANGES
-  return true;
-#else
-  return false;
-#endif
-}
-
 __global__ __launch_bounds__(1024) void tables_check_kernel(
     const double* ks, const double* vs, int ns, const double* ka, const double* va, int na,
     unsigned long long expect_hash_s, unsigned long long expect_hash_a, int expect_same,
-    unsigned long long* out) {
+    int fast_arithmetic, unsigned long long* out) {
   __shared__ unsigned long long s_hs[16], s_ha[16];
   __shared__ int s_diff[16];
+  __shared__ int s_odd[16];
   unsigned long long hs = 0, ha = 0;
   int diff = (ns != na) ? 1 : 0;
   bool odd = false; /* a key or a value the unwrapped arithmetic is not exact on */
@@ -800,9 +792,7 @@ __global__ __launch_bounds__(1024) void tables_check_kernel(
   for (int i = threadIdx.x; i < na; i += 1024) {
     odd = odd || !is_physical(ka[i]) || !is_physical(va[i]);
   }
-  if (__ballot(odd) != 0 && (threadIdx.x & 63) == 0) {
-    atomicOr(&out[4], 1ull);
-  }
+  const int wave_odd = (__ballot(odd) != 0) ? 1 : 0;
   for (int i = threadIdx.x; i < ns; i += 1024) {
     const unsigned long long k = (unsigned long long)__double_as_longlong(ks[i]);
     hs += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
@@ -827,30 +817,44 @@ __global__ __launch_bounds__(1024) void tables_check_kernel(
     s_hs[threadIdx.x >> 6] = hs;
     s_ha[threadIdx.x >> 6] = ha;
     s_diff[threadIdx.x >> 6] = diff;
+    s_odd[threadIdx.x >> 6] = wave_odd;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     hs = ha = 0;
     diff = 0;
+    int any_odd = 0;
     for (int w = 0; w < 16; ++w) {
       hs += s_hs[w];
       ha += s_ha[w];
       diff |= s_diff[w];
+      any_odd |= s_odd[w];
     }
     const int same = diff ? 0 : 1;
     out[1] = hs;
     out[2] = ha;
     out[3] = (unsigned long long)same;
-    out[0] = (hs != expect_hash_s || ha != expect_hash_a || same != expect_same) ? 1ull : 0ull;
+    out[4] = (unsigned long long)any_odd;
+    /* why the step's history kernels must not run as launched: [6] the host's view of
+     * the tables is stale; [7] the fast arithmetic was launched on input outside its
+     * proven range (out[5]: the densities, by unphysical_values_kernel earlier on this
+     * stream).  [0] is the abort flag the kernels read. */
+    const unsigned long long stale =
+        (hs != expect_hash_s || ha != expect_hash_a || same != expect_same) ? 1ull : 0ull;
+    const unsigned long long unproven = (fast_arithmetic && (any_odd || out[5] != 0)) ? 1ull : 0ull;
+    out[6] = stale;
+    out[7] = unproven;
+    out[0] = stale | unproven;
   }
 }
 
 hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
                                const double* va, int na, unsigned long long expect_hash_s,
                                unsigned long long expect_hash_a, int expect_same,
-                               unsigned long long* out4, hipStream_t stream) {
+                               int fast_arithmetic, unsigned long long* out4,
+                               hipStream_t stream) {
   hipLaunchKernelGGL(tables_check_kernel, dim3(1), dim3(1024), 0, stream, ks, vs, ns, ka, va, na,
-                     expect_hash_s, expect_hash_a, expect_same, out4);
+                     expect_hash_s, expect_hash_a, expect_same, fast_arithmetic, out4);
   return hipGetLastError();
 }
 
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void probe_cs_kernel(const double* keys, co
                                                      index_shift, index_base, energy[i])
                                 : cs_bracket(keys, nentries, energy[i]);
     index[i] = ind;
-    value[i] = cs_interpolate(keys, values, ind, energy[i]);
+    value[i] = cs_interpolate<false>(keys, values, ind, energy[i]);
   }
 }
 
@@ -1076,16 +1080,26 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
     };
     /* (the scalar-flux tally is a compile-time property of a kernel: the default
      * instantiations carry no trace of it) */
-    const int pick = (a.queue ? 4 : 0) | (a.same_tables ? 2 : 0) | (a.flux_tally ? 1 : 0);
+    /* (and so is the arithmetic policy, a.checked: neutral_device.h) */
+    const int pick = (a.checked ? 8 : 0) | (a.queue ? 4 : 0) | (a.same_tables ? 2 : 0) |
+                     (a.flux_tally ? 1 : 0);
     switch (pick) {
-      case 7: launch(history_regroup_kernel<true, true, true>); break;
-      case 6: launch(history_regroup_kernel<true, true, false>); break;
-      case 5: launch(history_regroup_kernel<false, true, true>); break;
-      case 4: launch(history_regroup_kernel<false, true, false>); break;
-      case 3: launch(history_regroup_kernel<true, false, true>); break;
-      case 2: launch(history_regroup_kernel<true, false, false>); break;
-      case 1: launch(history_regroup_kernel<false, false, true>); break;
-      default: launch(history_regroup_kernel<false, false, false>); break;
+      case 15: launch(history_regroup_kernel<true, true, true, true>); break;
+      case 14: launch(history_regroup_kernel<true, true, false, true>); break;
+      case 13: launch(history_regroup_kernel<false, true, true, true>); break;
+      case 12: launch(history_regroup_kernel<false, true, false, true>); break;
+      case 11: launch(history_regroup_kernel<true, false, true, true>); break;
+      case 10: launch(history_regroup_kernel<true, false, false, true>); break;
+      case 9: launch(history_regroup_kernel<false, false, true, true>); break;
+      case 8: launch(history_regroup_kernel<false, false, false, true>); break;
+      case 7: launch(history_regroup_kernel<true, true, true, false>); break;
+      case 6: launch(history_regroup_kernel<true, true, false, false>); break;
+      case 5: launch(history_regroup_kernel<false, true, true, false>); break;
+      case 4: launch(history_regroup_kernel<false, true, false, false>); break;
+      case 3: launch(history_regroup_kernel<true, false, true, false>); break;
+      case 2: launch(history_regroup_kernel<true, false, false, false>); break;
+      case 1: launch(history_regroup_kernel<false, false, true, false>); break;
+      default: launch(history_regroup_kernel<false, false, false, false>); break;
     }
     return hipGetLastError();
   }
@@ -1093,11 +1107,15 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
   auto launch1 = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, stream, a);
   };
-  switch ((a.same_tables ? 2 : 0) | (a.flux_tally ? 1 : 0)) {
-    case 3: launch1(history_kernel<true, true>); break;
-    case 2: launch1(history_kernel<true, false>); break;
-    case 1: launch1(history_kernel<false, true>); break;
-    default: launch1(history_kernel<false, false>); break;
+  switch ((a.checked ? 4 : 0) | (a.same_tables ? 2 : 0) | (a.flux_tally ? 1 : 0)) {
+    case 7: launch1(history_kernel<true, true, true>); break;
+    case 6: launch1(history_kernel<true, false, true>); break;
+    case 5: launch1(history_kernel<false, true, true>); break;
+    case 4: launch1(history_kernel<false, false, true>); break;
+    case 3: launch1(history_kernel<true, true, false>); break;
+    case 2: launch1(history_kernel<true, false, false>); break;
+    case 1: launch1(history_kernel<false, true, false>); break;
+    default: launch1(history_kernel<false, false, false>); break;
   }
   return hipGetLastError();
 }

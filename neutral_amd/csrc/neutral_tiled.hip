@@ -83,6 +83,12 @@ constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
 #define NEUTRAL_STREAM_REPEAT 64
 #endif
 constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
+/* (experiment switch: NEUTRAL_NO_CARRIED_TARGETS reads all four edges at every loop head) */
+#if defined(NEUTRAL_NO_CARRIED_TARGETS)
+constexpr bool kCarryTargets = false;
+#else
+constexpr bool kCarryTargets = true;
+#endif
 constexpr int kSortBlock = 256;
 /* counting sort: records one workgroup histograms and places at a time, and the
  * largest number of buckets (tiles + 1) it keeps in LDS (count + base: 64 KB);
@@ -564,7 +570,7 @@ __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window,
   }
 }
 
-template <bool kSameTables, bool kFlux, bool kDomain>
+template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
   constexpr int kWindows = kFlux ? 2 : 1;
@@ -708,9 +714,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               }
             }
             if (t.pass == 0) {
-              prologue<kSameTables>(h, a, ix);
+              prologue<kSameTables, kChecked>(h, a, ix);
             } else {
-              resume<kSameTables>(h, a, ix); /* a migrant: mid-history, no draw pending */
+              resume<kSameTables, kChecked>(h, a, ix); /* a migrant: mid-history, no draw pending */
             }
             if (!kDomain) {
               /* a history in this kernel has drawn once (collisions happen elsewhere), and
@@ -719,9 +725,15 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               h.counter = 1;
             }
             h.plain_div = 0;
-            refresh_speed_reciprocal(h); /* no collision here: the speed stays */
-            refresh_mfp_reciprocal(h);
-            decide(h, a);
+            refresh_speed_reciprocal<kChecked>(h); /* no collision here: the speed stays */
+            refresh_mfp_reciprocal<kChecked>(h);
+            if (kCarryTargets) {
+              load_targets(h, a);
+              decide_carried(h);
+              h.nevents++; /* (as decide() counts it) */
+            } else {
+              decide(h, a);
+            }
             has = true;
             if (h.ev == kEvCollision) {
               park = kRecCollide;
@@ -755,7 +767,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               break;
             }
             /* (tallies the cell it leaves: this one) */
-            cross_facet<true, kDomain ? 1 : 0>(h, a, cell_tally);
+            cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets>(h, a, cell_tally);
             if (kDomain) {
               /* the neighbour cell may belong to another rank: the history stops on the
                * facet, before anything of that cell (edges, density) is looked at */
@@ -765,7 +777,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                 break;
               }
             }
-            decide<false>(h, a);
+            if (kCarryTargets) {
+              decide_carried(h);
+            } else {
+              decide<false>(h, a);
+            }
             /* (selects, then one exit test: the nested form costs ~15 more scalar
              * exec-mask instructions per facet) */
             const bool goes_on = (h.ev == kEvFacet);
@@ -795,7 +811,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
         } else {
           if (h.ev == kEvCensus) {
-            census(h, a, tally);
+            census<kChecked>(h, a, tally);
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           store_record(h, a, t.rec_out[pid], kRecIdle);
@@ -1195,15 +1211,24 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
   };
   /* (scalar flux and spatial decomposition are compile-time properties of the kernel:
    * the default instantiation carries no trace of either) */
-  switch ((a.same_tables ? 4 : 0) | (a.flux_tally ? 2 : 0) | (a.decomposed ? 1 : 0)) {
-    case 7: launch(stream_kernel<true, true, true>); break;
-    case 6: launch(stream_kernel<true, true, false>); break;
-    case 5: launch(stream_kernel<true, false, true>); break;
-    case 4: launch(stream_kernel<true, false, false>); break;
-    case 3: launch(stream_kernel<false, true, true>); break;
-    case 2: launch(stream_kernel<false, true, false>); break;
-    case 1: launch(stream_kernel<false, false, true>); break;
-    default: launch(stream_kernel<false, false, false>); break;
+  switch ((a.checked ? 8 : 0) | (a.same_tables ? 4 : 0) | (a.flux_tally ? 2 : 0) |
+          (a.decomposed ? 1 : 0)) {
+    case 15: launch(stream_kernel<true, true, true, true>); break;
+    case 14: launch(stream_kernel<true, true, false, true>); break;
+    case 13: launch(stream_kernel<true, false, true, true>); break;
+    case 12: launch(stream_kernel<true, false, false, true>); break;
+    case 11: launch(stream_kernel<false, true, true, true>); break;
+    case 10: launch(stream_kernel<false, true, false, true>); break;
+    case 9: launch(stream_kernel<false, false, true, true>); break;
+    case 8: launch(stream_kernel<false, false, false, true>); break;
+    case 7: launch(stream_kernel<true, true, true, false>); break;
+    case 6: launch(stream_kernel<true, true, false, false>); break;
+    case 5: launch(stream_kernel<true, false, true, false>); break;
+    case 4: launch(stream_kernel<true, false, false, false>); break;
+    case 3: launch(stream_kernel<false, true, true, false>); break;
+    case 2: launch(stream_kernel<false, true, false, false>); break;
+    case 1: launch(stream_kernel<false, false, true, false>); break;
+    default: launch(stream_kernel<false, false, false, false>); break;
   }
   return hipGetLastError();
 }

@@ -66,7 +66,8 @@ class StepStats(C.Structure):
                 ("aborted", C.c_uint64), ("stream_passes", C.c_int),
                 ("requeued", C.c_uint64), ("collide_passes", C.c_uint64),
                 ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
-                ("tile_cells", C.c_int), ("export_ms", C.c_double)]
+                ("tile_cells", C.c_int), ("export_ms", C.c_double),
+                ("checked_arithmetic", C.c_int), ("attempts", C.c_int)]
 
 
 # every symbol include/neutral_hip.h declares
@@ -79,6 +80,7 @@ ABI_SYMBOLS = (
     "neutral_hip_device_count", "neutral_hip_set_device", "neutral_hip_set_stream",
     "neutral_hip_set_pid_base", "neutral_hip_get_pid_base", "neutral_hip_set_variant",
     "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
+    "neutral_hip_set_arithmetic",
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
     "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
     "neutral_hip_invalidate_particles", "neutral_hip_set_scalar_flux_tally",
@@ -121,6 +123,8 @@ _lib.neutral_hip_get_pid_base.restype = C.c_uint64
 _lib.neutral_hip_set_variant.restype = C.c_int
 _lib.neutral_hip_set_variant.argtypes = [C.c_int]
 _lib.neutral_hip_set_quiet.argtypes = [C.c_int]
+_lib.neutral_hip_set_arithmetic.restype = C.c_int
+_lib.neutral_hip_set_arithmetic.argtypes = [C.c_int]
 _lib.neutral_hip_set_tests_file.argtypes = [C.c_char_p]
 _lib.neutral_hip_last_step.argtypes = [C.POINTER(StepStats)]
 _lib.neutral_hip_reinject_particles.restype = None
@@ -228,6 +232,16 @@ def set_pid_base(pid_base: int) -> None:
 def set_variant(variant: int) -> None:
     if _lib.neutral_hip_set_variant(variant) != 0:
         raise ValueError(f"unknown kernel variant {variant}")
+
+
+ARITH_AUTO, ARITH_CHECKED = 0, 1
+
+
+def set_arithmetic(mode: int) -> None:
+    """ARITH_AUTO: the device picks the fast or the IEEE-checked kernels per step from the
+    step's density mesh and tables; ARITH_CHECKED: always the checked ones."""
+    if _lib.neutral_hip_set_arithmetic(mode) != 0:
+        raise ValueError(f"unknown arithmetic mode {mode}")
 
 
 def set_quiet(quiet: bool) -> None:

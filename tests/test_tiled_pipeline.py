@@ -279,31 +279,6 @@ def test_the_dead_keep_their_slots_and_cost_nothing(iface, make_problem, cs, laz
         assert all(x > y for x, y in zip(alive, alive[1:])), alive
 
 
-def test_unphysical_input_is_reported_once(iface, make_problem, cs, capfd):
-    """The default build's event bodies leave out range tests that cannot fire when every
-    density and table entry is positive and finite (the reference computes 0/0 otherwise).
-    The library checks that precondition itself -- the tables with their per-step check,
-    the density once per mesh -- and says so, once, when it does not hold."""
-    prob = make_problem("stream", nx=64, nparticles=4096, iterations=2)
-    iface.set_quiet(False)
-    try:
-        ok = iface.Simulation(prob, *cs, variant=2)
-        ok.inject()
-        ok.step(1)
-        ok.close()
-        assert "not positive and finite" not in capfd.readouterr().err
-        sim = iface.Simulation(prob, *cs, variant=2)
-        sim.inject()
-        sim.density[5] = 0.0   # a cell of true vacuum (the decks use 1e-30 for a reason)
-        sim.step(1)
-        sim.step(2)
-        sim.close()
-        err = capfd.readouterr().err
-        assert err.count("not positive and finite") == 1 and "density" in err
-    finally:
-        iface.set_quiet(True)
-
-
 def test_two_live_stores_under_lazy_export(iface, make_problem, cs):
     """The record workspace is shared: stepping a second, larger store must first
     write the first store's pending state back (round-1 advisor finding)."""

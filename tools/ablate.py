@@ -103,7 +103,8 @@ def single(argv):
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) * 1e3
         tag = os.path.basename(os.environ.get("NEUTRAL_HIP_LIB", "default"))
-        print(f"{tag:40s} {deck} nx={nx} n={n}: {tot_ms:9.1f} ms  {tot_steps / tot_ms / 1e6:8.3f} Gsteps/s"
+        vname = {0: "K1 over-particle", 1: "K2 event-regrouped", 2: "K3 tiled", None: "K3 tiled"}[variant]
+        print(f"{tag:24s} {vname:18s} {deck} nx={nx} n={n}: {tot_ms:9.1f} ms  {tot_steps / tot_ms / 1e6:8.3f} Gsteps/s"
               f"  wall {wall_ms:.1f} ms (write-back pass {export_ms:.1f})"
               f"  tally={float(sim.tally.sum()):.6e}  sort/stream/collide "
               f"{stages[0]:.1f}/{stages[1]:.1f}/{stages[2]:.1f}  per-step ms: {' '.join(per)}",

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Static opcode histogram of a kernel's hot loop, from the ISA listing `make -C neutral_amd asm`
+leaves in neutral_amd/build/*.s, priced with the issue cost per opcode measured on the box
+(profiles/r03/valu_peak.log, tools/micro/valu_peak.hip).
+
+The hot loop is found, not assumed: the innermost loop (a label and a backward branch to
+it) that contains at least --min-marker instructions matching --marker (v_alignbit_b32 for
+the collision pass: Threefry's rotations; ds_add_f64 for the facet loop: the LDS tally).
+
+  python tools/isa_histogram.py collide     # history_regroup_kernel<true,true,false,false>
+  python tools/isa_histogram.py facet       # stream_kernel<true,false,false,false>
+  python tools/isa_histogram.py collide --json
+"""
+import argparse
+import collections
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "neutral_amd", "build")
+
+TARGETS = {
+    "collide": ("neutral_kernels-hip-amdgcn-amd-amdhsa-gfx950.s",
+                "_ZN7neutral22history_regroup_kernelILb1ELb1ELb0ELb0EEEvNS_9SolveArgsE",
+                r"v_alignbit_b32", 60),
+    "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
+              "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
+              r"ds_add_f64", 1),
+}
+
+# Issue cycles one wave64 instruction holds its SIMD for, by opcode, measured with
+# tools/micro/valu_peak.hip at 4 waves per SIMD (profiles/r03/valu_peak.log).  Opcodes
+# not listed fall back by family (see cost_of).
+MEASURED = os.path.join(ROOT, "profiles", "valu_cycles.json")
+
+
+def load_costs():
+    try:
+        with open(MEASURED) as f:
+            return json.load(f)["cycles"]
+    except OSError:
+        return {}
+
+
+def base_op(op):
+    return re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+
+
+def cost_of(op, costs):
+    """(cycles, how) for a VALU opcode: measured, or the family rule."""
+    b = base_op(op)
+    if b in costs:
+        return costs[b], "measured"
+    if re.search(r"_(rcp|rsq|sqrt)_f64", b):
+        return costs.get("v_rcp_f64", 16.0), "family"
+    if re.search(r"(_f64|_u64|_i64|_b64)\b", b) or b.startswith("v_cvt_"):
+        return 4.0, "family"
+    return costs.get("v_xor_b32", 2.0), "family"
+
+
+def function_body(path, symbol):
+    src = open(path).read()
+    i = src.index(symbol + ":")
+    j = src.index(".Lfunc_end", i)
+    return src[i:j].splitlines()
+
+
+def parse(body):
+    """[(label or None, opcode or None, text)] per line"""
+    out = []
+    for line in body:
+        t = line.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            out.append((m.group(1), None, t))
+            continue
+        m = re.match(r"^([vs]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+|flat_[a-z0-9_]+|"
+                     r"buffer_[a-z0-9_]+|scratch_[a-z0-9_]+)\b", t)
+        if m:
+            out.append((None, m.group(1), t))
+    return out
+
+
+def loops(items):
+    """(start, end) index pairs: a label and a later branch back to it"""
+    pos = {lab: k for k, (lab, _, _) in enumerate(items) if lab}
+    out = []
+    for k, (_, op, text) in enumerate(items):
+        if op and op.startswith(("s_cbranch", "s_branch")):
+            m = re.search(r"(\.LBB\d+_\d+)", text)
+            if m and m.group(1) in pos and pos[m.group(1)] < k:
+                out.append((pos[m.group(1)], k))
+    return out
+
+
+def hot_loop(items, marker, min_marker):
+    best = None
+    for a, b in loops(items):
+        n = sum(1 for _, op, _ in items[a:b + 1] if op and re.match(marker, op))
+        if n >= min_marker and (best is None or (b - a) < (best[1] - best[0])):
+            best = (a, b)
+    if best is None:
+        raise SystemExit("no loop with the marker found")
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("target", choices=sorted(TARGETS))
+    ap.add_argument("--json", action="store_true")
+    ap.add_argument("--dump", action="store_true", help="print the loop's instructions")
+    args = ap.parse_args()
+    fname, symbol, marker, min_marker = TARGETS[args.target]
+    items = parse(function_body(os.path.join(BUILD, fname), symbol))
+    a, b = hot_loop(items, marker, min_marker)
+    span = items[a:b + 1]
+    if args.dump:
+        for lab, op, text in span:
+            print(text)
+        return
+    costs = load_costs()
+    valu = collections.Counter(op for _, op, _ in span if op and op.startswith("v_")
+                               and not op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")))
+    salu = sum(1 for _, op, _ in span if op and op.startswith("s_"))
+    mem = collections.Counter(op for _, op, _ in span
+                              if op and op.startswith(("ds_", "global_", "flat_", "scratch_", "buffer_")))
+    rows, cycles, by_how = [], 0.0, collections.Counter()
+    for op, n in valu.most_common():
+        c, how = cost_of(op, costs)
+        rows.append({"op": op, "count": n, "cycles_each": c, "priced": how})
+        cycles += n * c
+        by_how[how] += n * c
+    nvalu = sum(valu.values())
+    out = {"target": args.target, "symbol": symbol,
+           "loop": {"first_label": span[0][0], "instructions": sum(1 for _, op, _ in span if op)},
+           "valu_instructions": nvalu, "salu_instructions": salu, "memory_instructions": dict(mem),
+           "issue_cycles": cycles, "mean_cycles_per_valu": cycles / max(nvalu, 1),
+           "cycles_priced_by_measurement": by_how["measured"] / max(cycles, 1e-9),
+           "opcodes": rows}
+    if args.json:
+        print(json.dumps(out, indent=1))
+        return
+    print(f"{args.target}: loop at {span[0][0]}, {out['loop']['instructions']} instructions: "
+          f"{nvalu} VALU, {salu} SALU, {sum(mem.values())} memory")
+    for r in rows:
+        print(f"  {r['op']:28s} {r['count']:4d} x {r['cycles_each']:5.2f}  ({r['priced']})")
+    print(f"  issue cycles per trip {cycles:.0f}; mean {cycles / max(nvalu, 1):.2f} per VALU instruction; "
+          f"{100 * out['cycles_priced_by_measurement']:.0f} % of the cycles priced by a measured opcode")
+
+
+if __name__ == "__main__":
+    main()
