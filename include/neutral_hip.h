@@ -186,6 +186,13 @@ typedef struct {
   int attempts;          /* times the step's kernels were enqueued (1 in steady state; +1
                             when the device-side check turned the attempt down: a table
                             rewritten in place, input outside the proven range) */
+  int host_collectives;  /* several ranks: collectives over the ranks' host links that the
+                            step made of its own, beside the exchange itself (which is RCCL on
+                            the kernels' stream, or staged through those links as a fallback).
+                            0 in steady state: event counters and the flags the ranks act on
+                            together travel with the tally, on the device.  A decomposed mesh
+                            counts the rounds of its particle exchange here */
+  int exchange_ranks;    /* ranks the last tally exchange summed over (1: no exchange) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

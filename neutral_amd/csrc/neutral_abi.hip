@@ -27,7 +27,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 6 /* 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic + attempts; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 6 /* 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
@@ -117,6 +117,10 @@ struct State {
   int plan_passes = 0;
   bool slots_valid = false;        /* tiled.slot_of_id describes tiled.rec_in */
   int host_syncs = 0;              /* waits for the device inside the current call */
+  int host_collectives = 0;        /* collectives over the ranks' host links inside the current
+                                      call, the staging of the exchange itself not counted */
+  unsigned long long* d_words = nullptr; /* several ranks: the step's words (event counters,
+                                            flags) that travel with the tally exchange */
   /* ranks: particle stores made by inject_particles (this rank's shards) and the
    * per-step tally that is all-reduced before it joins the caller's mesh */
   double* flux_tally = nullptr; /* scalar-flux tally of the caller (null: not kept) */
@@ -177,6 +181,7 @@ void ensure_scratch() {
   HIP_CHECK(hipMemset(g.d_check, 0, 8 * sizeof(unsigned long long)));
   HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
   HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));
+  HIP_CHECK(hipMalloc((void**)&g.d_words, sizeof(unsigned long long) * 16));
   g.tables.valid = false; /* its indexes live in the other device's scratch */
   HIP_CHECK(hipMalloc((void**)&g.d_index_fine,
                       sizeof(unsigned short) * (kMaxFineIndexBuckets + 1)));
@@ -457,14 +462,42 @@ neutral::ParticleView view_of(const NeutralHipParticle* p) {
   return v;
 }
 
-/* true on every rank when the condition holds on any (one rank: the condition itself) */
-bool any_rank(bool mine) {
-  if (neutral::comm_nranks() == 1) {
-    return mine;
+/* What the ranks need of each other per batch of launches besides the tally: the event
+ * counters and the flags every rank must act on together (an attempt turned down, stream
+ * passes still owed).  Packed on the device, summed by the same transport as the tally on
+ * the same stream, read with the batch's single wait: a steady-state step makes no
+ * collective over the host links of its own. */
+enum StepWord : int {
+  kWordCounters = 0,   /* 2 x {nprocessed, nfacets, ncollisions, ncensus} */
+  kWordRequeued = 8,
+  kWordCollidePasses = 9,
+  kWordTurnedDown = 10, /* ranks whose attempt was turned down on the device */
+  kWordMigrants = 11,   /* histories still waiting for a stream pass */
+  kWordQueued = 12,     /* histories this batch's collision stage was handed */
+  kWordAborted = 13,
+  kWordRanks = 14,      /* 1 per rank: how many ranks the transport summed over */
+  kStepWords = 16,
+};
+
+__global__ void pack_step_words_kernel(const neutral::StepCounters* c, const unsigned long long* check,
+                                       const unsigned* ctrl, unsigned long long* w) {
+  if (threadIdx.x != 0) {
+    return;
   }
-  uint64_t v = mine ? 1u : 0u;
-  comms_allreduce_u64(&v, 1, COMMS_MAX);
-  return v != 0;
+  for (int k = 0; k < 2; ++k) {
+    w[kWordCounters + 4 * k + 0] = c[k].nprocessed;
+    w[kWordCounters + 4 * k + 1] = c[k].nfacets;
+    w[kWordCounters + 4 * k + 2] = c[k].ncollisions;
+    w[kWordCounters + 4 * k + 3] = c[k].ncensus;
+  }
+  w[kWordRequeued] = c[0].nrequeued + c[1].nrequeued;
+  w[kWordCollidePasses] = c[0].ncollide_passes + c[1].ncollide_passes;
+  w[kWordTurnedDown] = check[0] ? 1ull : 0ull;
+  w[kWordMigrants] = ctrl ? ctrl[4] : 0u;
+  w[kWordQueued] = ctrl ? ctrl[2] : 0u;
+  w[kWordAborted] = (unsigned long long)c[0].aborted + c[1].aborted;
+  w[kWordRanks] = 1ull;
+  w[15] = 0ull;
 }
 
 __global__ void add_step_tally_kernel(double* __restrict__ tally, const double* __restrict__ step,
@@ -480,8 +513,12 @@ __global__ void add_step_tally_kernel(double* __restrict__ tally, const double* 
  * mesh, which then holds the same global tally on every rank.  The step buffer is
  * cleared again, so a step that needs more stream passes than were enqueued simply
  * exchanges what those add. */
-void exchange_step(const neutral::SolveArgs& a, double* tally) {
+void exchange_step(const neutral::SolveArgs& a, double* tally, bool tiled) {
   const size_t ncells = (size_t)a.nx * (size_t)a.ny;
+  hipLaunchKernelGGL(pack_step_words_kernel, dim3(1), dim3(64), 0, g.stream, g.d_counters, g.d_check,
+                     tiled ? (const unsigned*)g.tiled.ctrl : (const unsigned*)nullptr, g.d_words);
+  HIP_CHECK(hipGetLastError());
+  neutral::comm_allreduce_sum(g.d_words, (size_t)kStepWords, false, g.stream);
   neutral::comm_allreduce_sum(a.tally, ncells, true, g.stream);
   hipLaunchKernelGGL(add_step_tally_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
                      g.stream, tally, (const double*)a.tally, ncells);
@@ -532,6 +569,7 @@ int exchange_particles(const neutral::SolveArgs& a, neutral::TiledArgs& t) {
     exit(EXIT_FAILURE);
   }
   comms_allreduce_u64(matrix, (size_t)n * n, COMMS_SUM);
+  g.host_collectives++;
   size_t in = 0;
   for (int s2 = 0; s2 < n; ++s2) {
     in += (size_t)(matrix[(size_t)s2 * n + me] / sizeof(neutral::ParticleRec));
@@ -883,6 +921,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
 
   neutral::StepCounters hc[2];
   unsigned ctrl[16] = {0};
+  unsigned long long words[kStepWords] = {0}; /* several ranks: the global step words */
+  g.host_collectives = 0;
   int passes = 0;
   int same = 0;
   int attempts = 0;
@@ -1004,7 +1044,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
 
     if (exchange) {
-      exchange_step(a, energy_deposition_tally);
+      exchange_step(a, energy_deposition_tally, tiled);
+      HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
     }
     /* the one wait of a steady-state step: counters, the pipeline's control words
      * and the verdict on the table view */
@@ -1038,7 +1079,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
     /* (several ranks take every decision that leads to another exchange together:
      * the collectives must pair up) */
-    if (!(decomposed ? check[0] != 0 : any_rank(check[0] != 0))) {
+    const bool turned_down = decomposed ? check[0] != 0
+                                        : (exchange ? words[kWordTurnedDown] != 0 : check[0] != 0);
+    if (!turned_down) {
       break;
     }
     if (attempt >= 3) {
@@ -1048,16 +1091,16 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     }
   }
 
-  unsigned long long queue_total = ctrl[2];
+  const bool exchange = neutral::comm_nranks() > 1 && !decomposed;
+  unsigned long long queue_total = exchange ? words[kWordQueued] : ctrl[2];
   if (tiled) {
-    const bool exchange = neutral::comm_nranks() > 1 && !decomposed;
     /* Finishes what is enqueued: migrants left over mean the step outran the plan (it
      * needs more stream passes than the last one did).  More passes, as many again as
      * have run; the histories they suspend get a collision stage of their own (the
      * first one's are marked done), and with several ranks their tallies an exchange
      * of their own. */
     auto finish_passes = [&]() {
-      while (exchange ? any_rank(ctrl[4] != 0) : (ctrl[4] != 0)) {
+      while (exchange ? (words[kWordMigrants] != 0) : (ctrl[4] != 0)) {
         neutral::TiledPlan more = {passes < 2 ? 2 : passes, -1};
         HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
@@ -1070,14 +1113,15 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         }
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {
-          exchange_step(a, energy_deposition_tally);
+          exchange_step(a, energy_deposition_tally, tiled);
+          HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
         }
         HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
         HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
                                  g.stream));
         wait_for_stream();
         harvest(false);
-        queue_total += ctrl[2];
+        queue_total += exchange ? words[kWordQueued] : ctrl[2];
       }
     };
     finish_passes();
@@ -1088,6 +1132,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       for (;;) {
         uint64_t waiting = ctrl[7];
         comms_allreduce_u64(&waiting, 1, COMMS_SUM);
+        g.host_collectives++;
         if (waiting == 0) {
           break;
         }
@@ -1159,8 +1204,22 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   const double ms = stage.kernel, ms_sort = stage.sort, ms_stream = stage.stream,
                ms_collide = stage.collide, ms_export = stage.exported;
 
-  if (neutral::comm_nranks() > 1) {
-    /* event counters of all ranks (a handful of words: over the host links) */
+  if (exchange) {
+    /* event counters of all ranks: they travelled with the tally (StepWord) */
+    for (int k = 0; k < 2; ++k) {
+      hc[k].nprocessed = words[kWordCounters + 4 * k + 0];
+      hc[k].nfacets = words[kWordCounters + 4 * k + 1];
+      hc[k].ncollisions = words[kWordCounters + 4 * k + 2];
+      hc[k].ncensus = words[kWordCounters + 4 * k + 3];
+    }
+    hc[0].nrequeued = 0;
+    hc[1].nrequeued = words[kWordRequeued];
+    hc[0].ncollide_passes = 0;
+    hc[1].ncollide_passes = words[kWordCollidePasses];
+    hc[0].aborted = 0;
+    hc[1].aborted = (unsigned)words[kWordAborted];
+  } else if (neutral::comm_nranks() > 1) {
+    /* decomposed mesh: a handful of words over the host links, like its other exchanges */
     static_assert(sizeof(hc) % 8 == 0, "StepCounters is summed word by word");
     const unsigned aborted[2] = {hc[0].aborted, hc[1].aborted};
     comms_allreduce_u64((uint64_t*)hc, sizeof(hc) / 8, COMMS_SUM);
@@ -1169,6 +1228,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     uint64_t q = queue_total;
     comms_allreduce_u64(&q, 1, COMMS_SUM);
     queue_total = q;
+    g.host_collectives += 2;
   }
   neutral::StepCounters h = hc[0];
   h.nprocessed += hc[1].nprocessed;
@@ -1206,6 +1266,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.export_ms = (double)ms_export;
   g.last.checked_arithmetic = checked ? 1 : 0;
   g.last.attempts = attempts;
+  g.last.host_collectives = g.host_collectives;
+  g.last.exchange_ranks = exchange ? (int)words[kWordRanks] : 1;
 
   if (!g.quiet) {
     printf("Particles  %llu\n", (unsigned long long)h.nprocessed); /* omp3/neutral.c:205 */

@@ -67,7 +67,8 @@ class StepStats(C.Structure):
                 ("requeued", C.c_uint64), ("collide_passes", C.c_uint64),
                 ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
                 ("tile_cells", C.c_int), ("export_ms", C.c_double),
-                ("checked_arithmetic", C.c_int), ("attempts", C.c_int)]
+                ("checked_arithmetic", C.c_int), ("attempts", C.c_int),
+                ("host_collectives", C.c_int), ("exchange_ranks", C.c_int)]
 
 
 # every symbol include/neutral_hip.h declares

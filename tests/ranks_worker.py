@@ -31,12 +31,14 @@ def main():
     sim = iface.Simulation(prob, keys, values, variant=2,
                            domain=(px, py) if mode == "domain" else None, scalar_flux=flux)
     sim.inject()
-    events, counts, syncs = [], [sim.n], []
+    events, counts, syncs, collectives, summed_over = [], [sim.n], [], [], []
     for tt in range(1, steps + 1):
         r = sim.step(tt)
         events.append((r.nprocessed, r.facets, r.collisions, r.census))
         counts.append(sim.n)
         syncs.append(r.stats.host_syncs)
+        collectives.append(r.stats.host_collectives)
+        summed_over.append(r.stats.exchange_ranks)
     arrays = sim.particle_arrays()
     ids = sim.particle_keys() if mode == "domain" else \
         (np.arange(sim.n, dtype=np.uint32) + np.uint32(sim.pid_base))
@@ -49,7 +51,8 @@ def main():
     sim.close()
     iface.library().neutral_hip_comm_barrier()
     iface.library().neutral_hip_comm_stop()
-    print(json.dumps({"rank": rank, "counts": counts, "syncs": syncs}))
+    print(json.dumps({"rank": rank, "counts": counts, "syncs": syncs, "collectives": collectives,
+                      "exchange_ranks": summed_over}))
 
 
 if __name__ == "__main__":

@@ -189,6 +189,25 @@ def test_decomposed_run_with_the_scalar_flux(tmp_path, cs):
     assert np.linalg.norm(got_f - want_f) / np.linalg.norm(want_f) < 1e-13
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_steps_make_no_host_collectives(tmp_path, cs, nranks):
+    """Particle shards over 2 and 3 ranks, five csp steps (the first two need more stream
+    passes than the plan enqueues: batches, each ending in an exchange): per-step event
+    counts equal the oracle's, NeutralHipStepStats.host_collectives is 0 in every step and
+    a steady-state step waits for the device once."""
+    from neutral_amd import decks
+    path = decks.write_deck("csp", str(tmp_path / "csp.params"), nx=128, ny=128, nparticles=60001,
+                            iterations=5, dt=1.0e-6)
+    _, orc_t, _, orc_ev = _oracle(path, cs, 5)
+    ranks, logs = _run_ranks(path, str(tmp_path), 5, nranks, 1, mode="shard")
+    for r, lg in zip(ranks, logs):
+        assert [tuple(e) for e in r["events"]] == orc_ev
+        assert lg["collectives"] == [0] * 5, lg
+        assert lg["exchange_ranks"] == [nranks] * 5, lg
+        _assert_mesh_matches_oracle(r["tally"].reshape(128, 128), orc_t)
+    assert min(lg["syncs"][-1] for lg in logs) >= 1
+
+
 def test_sharded_ranks_with_the_scalar_flux(tmp_path, cs):
     """Particle shards (the mesh replicated): energy tally AND scalar flux are all-reduced
     per step, so every rank ends with both global meshes."""
@@ -197,8 +216,14 @@ def test_sharded_ranks_with_the_scalar_flux(tmp_path, cs):
                             iterations=2, dt=1.0e-6)
     orc_p, orc_t, orc_f, orc_ev = _oracle(path, cs, 2, flux=True)
     want_p, want_t, want_f, want_ev, _ = _reference(path, cs, 2, flux=True)
-    ranks, _ = _run_ranks(path, str(tmp_path), 2, 3, 1, mode="shard", extra=("flux",))
+    ranks, logs = _run_ranks(path, str(tmp_path), 2, 3, 1, mode="shard", extra=("flux",))
     assert sum(len(r["ids"]) for r in ranks) == 30001
+    # event counters and the flags the ranks act on together travel with the tally, on the
+    # device: no collective over the host links of the step's own, and the exchange summed
+    # over all three ranks
+    for lg in logs:
+        assert lg["collectives"] == [0, 0], lg
+        assert lg["exchange_ranks"] == [3, 3], lg
     for r in ranks:
         # against the oracle: every rank holds the all-reduced global meshes
         assert [tuple(e) for e in r["events"]] == orc_ev

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Static opcode histogram of a kernel's hot loop, from the ISA listing `make -C neutral_amd asm`
 leaves in neutral_amd/build/*.s, priced with the issue cost per opcode measured on the box
-(profiles/r03/valu_peak.log, tools/micro/valu_peak.hip).
+(profiles/valu_cycles.json, tools/micro/valu_opcodes.hip).
 
 The hot loop is found, not assumed: the innermost loop (a label and a backward branch to
 it) that contains at least --min-marker instructions matching --marker (v_alignbit_b32 for
-the collision pass: Threefry's rotations; ds_add_f64 for the facet loop: the LDS tally).
+the collision pass: Threefry's rotations; v_mul_f64 for the facet loop: the smallest loop
+with a dozen of them is the facet trip).
 
   python tools/isa_histogram.py collide     # history_regroup_kernel<true,true,false,false>
   python tools/isa_histogram.py facet       # stream_kernel<true,false,false,false>
@@ -26,12 +27,12 @@ TARGETS = {
                 r"v_alignbit_b32", 60),
     "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
               "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-              r"ds_add_f64", 1),
+              r"v_mul_f64", 12),
 }
 
 # Issue cycles one wave64 instruction holds its SIMD for, by opcode, measured with
-# tools/micro/valu_peak.hip at 4 waves per SIMD (profiles/r03/valu_peak.log).  Opcodes
-# not listed fall back by family (see cost_of).
+# tools/micro/valu_opcodes.hip at 4 waves per SIMD, relative to v_mul_f64 = 4.  Opcodes not
+# listed fall back by family (see cost_of).
 MEASURED = os.path.join(ROOT, "profiles", "valu_cycles.json")
 
 
@@ -50,8 +51,15 @@ def base_op(op):
 def cost_of(op, costs):
     """(cycles, how) for a VALU opcode: measured, or the family rule."""
     b = base_op(op)
+    if b == "v_cndmask_b32":
+        # back to back the VOP2 form measures ~20 cycles; in the kernels it costs what the
+        # VOP3 form costs (profiles/r03/experiments/retune_isa_ab.log)
+        return costs.get("v_cndmask_b32_e64", 4.0), "measured"
     if b in costs:
         return costs[b], "measured"
+    for enc in ("_e64", "_e32"):  # compares are measured per encoding
+        if b + enc in costs:
+            return costs[b + enc], "measured"
     if re.search(r"_(rcp|rsq|sqrt)_f64", b):
         return costs.get("v_rcp_f64", 16.0), "family"
     if re.search(r"(_f64|_u64|_i64|_b64)\b", b) or b.startswith("v_cvt_"):
