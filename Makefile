@@ -12,7 +12,7 @@ test-cpu: all
 pin-kats: test-cpu
 	{ echo "# make test-cpu at $$(git rev-parse --short HEAD)$$(git diff --quiet || echo +dirty), $$(date -u +%Y-%m-%dT%H:%MZ)"; \
 	  echo "# oracle/neutral_oracle.c sha256 $$(sha256sum oracle/neutral_oracle.c | cut -c1-16)"; \
-	  grep -E "PASSED|FAILED|SKIPPED|passed|failed" oracle/pins/_latest.log; } > oracle/pins/full_kats.log
+	  grep -E "PASSED|FAILED|SKIPPED|passed|failed|tally=" oracle/pins/_latest.log; } > oracle/pins/full_kats.log
 
 test-gpu: all
 	python -m pytest tests -x -q -m gpu

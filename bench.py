@@ -45,15 +45,21 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 # vector issue: 256 CUs x 4 SIMDs, 2.4 GHz (MI355X_MICROARCH.md)
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
-# cycles one wave64 instruction holds its SIMD's vector issue, measured per class with
-# tools/micro/valu_peak.hip at 3-4 waves per SIMD (profiles/r02/valu_peak.log):
-#   f64 add/mul/fma, 64-bit integer add, f64 conversions, v_alignbit_b32, v_add_co_u32   4
-#   v_rcp/rsq/sqrt_f64                                                                   16
-#   plain 32-bit ops (v_xor_b32, v_add_u32, v_mov_b32, v_fma_f32)                        2.2-2.4
-# The PMC classes do not separate the 2- from the 4-cycle 32-bit instructions, so the
-# issue cycles of a launch are bracketed: every instruction outside the f64/int64/cvt/
-# transcendental classes priced at 2 cycles (lower bound: `frac`) or at 4 (upper).
-CYCLES_FULL, CYCLES_TRANS, CYCLES_SHORT = 4.0, 16.0, 2.0
+# Cycles one wave64 instruction holds its SIMD's vector issue: measured PER OPCODE for every
+# opcode of the two hot loops (tools/micro/valu_opcodes.hip -> profiles/valu_cycles.json, four
+# waves per SIMD, v_mul_f64 = 4): f64 arithmetic, 64-bit integer adds, conversions, compares,
+# v_alignbit_b32, v_cndmask_b32, three-operand and carry 32-bit ops 3.5-4.4; v_rcp/rsq_f64
+# 13.5; plain two-operand 32-bit ops (v_xor_b32, v_add_u32, v_mov_b32 ...) 2.3-2.5.  The PMC
+# instruction classes cannot tell a 2.4-cycle v_xor_b32 from a 3.6-cycle v_alignbit_b32, the
+# listing can: tools/isa_histogram.py prices the hot loop of each kernel opcode by opcode
+# (profiles/isa_mix.json: mean issue cycles per vector instruction of the collision pass and
+# of the facet trip), and the roofline is
+#     wave-level vector instructions of the launch (PMC, per event x this run's events)
+#       x mean cycles per instruction of the kernel's hot loop
+#       / (kernel time x 1024 SIMDs x 2.4 GHz).
+# What is left of a bracket is the share of the loop's cycles priced by an opcode FAMILY
+# rule instead of a measurement (a few compares): those at 2 cycles (`frac_low`) or at their
+# family's cost (`frac`, `frac_high` with them at 4.4).
 
 WORKLOADS = {
     # name: (deck, nx, nparticles, deck iterations)
@@ -134,39 +140,56 @@ def profile_entry(deck, nx, variant, kernel):
     return None
 
 
-def issue_roofline(deck, nx, variant, kernel, ev, launches):
-    """Vector-issue roofline of one kernel: issue cycles of THIS run's launches (per-event
-    PMC coefficients x this run's events) over the SIMD cycles its measured duration
-    offers."""
+HOT_LOOP = {"stream_kernel": "facet", "history_regroup_kernel": "collide",
+            "history_kernel": "collide"}
+
+
+def isa_mix(kernel):
+    """Mean issue cycles per vector instruction of the kernel's hot loop and how much of
+    that is priced by measured opcodes (profiles/isa_mix.json, tools/isa_histogram.py)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
+            return json.load(f).get(HOT_LOOP.get(kernel, ""))
+    except OSError:
+        return None
+
+
+def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None):
+    """Vector-issue roofline of one kernel: issue cycles of THIS run's launches (wave-level
+    vector instructions per event from the committed PMC passes x this run's events x the
+    mean cost of an instruction of the kernel's hot loop, priced opcode by opcode) over
+    the SIMD cycles its measured duration offers."""
     e = profile_entry(deck, nx, variant, kernel)
+    mix = isa_mix(kernel)
     n = ev[PRIMARY_EVENT[kernel]]
-    if e is None or n == 0 or ev["ms"] <= 0:
+    if e is None or mix is None or n == 0 or ev["ms"] <= 0:
         return None
     c = e["per_event"]
     insts = c["SQ_INSTS_VALU"] * n
-    trans = c.get("SQ_INSTS_VALU_TRANS_F64", 0.0) * n
-    full = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64",
-                                       "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_INT64",
-                                       "SQ_INSTS_VALU_CVT")) * n
-    short = max(0.0, insts - trans - full)
-    lo = CYCLES_FULL * full + CYCLES_TRANS * trans + CYCLES_SHORT * short
-    hi = CYCLES_FULL * (full + short) + CYCLES_TRANS * trans
+    mean, lo_mean, hi_mean = (mix["mean_cycles_per_valu"], mix["mean_cycles_per_valu_low"],
+                              mix["mean_cycles_per_valu_high"])
     seconds = ev["ms"] * 1e-3
     avail = SIMD_CYCLES_PER_S * seconds
     out = {"bound": "valu_issue", "kernel": kernel,
-           "achieved": lo / seconds / 1e9, "peak": SIMD_CYCLES_PER_S / 1e9,
-           "unit": "G SIMD issue cycles/s", "frac": lo / avail,
-           "frac_if_every_32bit_op_took_4_cycles": hi / avail,
+           "achieved": insts * mean / seconds / 1e9, "peak": SIMD_CYCLES_PER_S / 1e9,
+           "unit": "G SIMD issue cycles/s", "frac": insts * mean / avail,
+           "frac_low": insts * lo_mean / avail, "frac_high": insts * hi_mean / avail,
            "kernel_ms_avg": ev["ms"] / launches,
            "wave_valu_insts_per_launch": insts / launches,
-           "f64_int64_cvt_insts_per_launch": full / launches,
-           "quarter_rate_f64_insts_per_launch": trans / launches,
-           "other_insts_per_launch": short / launches,
+           "mean_issue_cycles_per_valu_inst": mean,
+           "share_of_loop_cycles_priced_by_measured_opcodes": mix["cycles_priced_by_measurement"],
            "valu_insts_per_event": c["SQ_INSTS_VALU"], "event": PRIMARY_EVENT[kernel],
            "events_per_launch": n / launches,
-           "pricing": "cycles per wave64 instruction: 4 (f64, int64, cvt), 16 (rcp/rsq/sqrt "
-                      "f64), 2 (everything else: lower bound; tools/micro/valu_peak.hip)",
+           "pricing": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU per event x this run's "
+                      "events; cycles per instruction: the hot loop's opcodes (tools/isa_histogram.py "
+                      "on the shipped ISA) x the issue cost measured per opcode "
+                      "(tools/micro/valu_opcodes.hip, v_mul_f64 = 4); clock 2.4 GHz nominal",
            "profiled": e.get("source", "profiles/pmc_per_event.json")}
+    if collide_passes and HOT_LOOP.get(kernel) == "collide":
+        # the same figure from the kernel's own dynamic count: wave-level collision passes
+        # x the static issue cycles of one trip of the pass loop (rare paths included)
+        out["frac_from_pass_count"] = collide_passes * mix["issue_cycles_per_trip"] / avail
+        out["collision_passes_per_launch"] = collide_passes / launches
     if c.get("SQ_ACTIVE_INST_VALU"):
         out["lane_utilisation"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / \
             (c["SQ_ACTIVE_INST_VALU"] * 64.0)
@@ -202,6 +225,28 @@ def hbm_view(deck, nx, variant, kernel, ev, launches, same_tables):
         out["l2_requests_per_event"] = c["TCC_REQ_sum"]
         out["l2_atomics_per_event"] = c.get("TCC_ATOMIC_sum", 0.0)
     return out
+
+
+def one_rank_path():
+    # (NEUTRAL_ONE_RANK_RECORD: another file, for the tests)
+    return os.environ.get("NEUTRAL_ONE_RANK_RECORD") or \
+        os.path.join(ROOT, "profiles", "one_rank_tally.json")
+
+
+def one_rank_record(deck, nx, nparticles, steps):
+    """What ONE rank computes for this workload and step count (profiles/one_rank_tally.json:
+    event totals and the global tally of `bench.py --gpus 1`, recorded on the GPU box): the
+    N > 1 bench line is checked against it -- event counts exactly, the all-reduced tally to
+    1e-12 (summation order) -- because a run over several GPUs has no CPU leg of its own."""
+    try:
+        with open(one_rank_path()) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    for e in table.get("entries", []):
+        if (e["deck"], e["nx"], e["nparticles"], e["steps"]) == (deck, nx, nparticles, steps):
+            return e
+    return None
 
 
 def measured_copy_bandwidth(device):
@@ -243,6 +288,9 @@ def parse_args():
                     help="tally exchange for N > 1: RCCL over xGMI, or staged through the host")
     ap.add_argument("--share-device", action="store_true",
                     help="testing only: every rank uses GPU 0 (needs --comm host)")
+    ap.add_argument("--record-one-rank", action="store_true",
+                    help="N = 1: write this run's event totals and global tally to "
+                         "profiles/one_rank_tally.json (what N > 1 lines are checked against)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work of the cpu_baseline sample")
     return ap.parse_args()
@@ -435,7 +483,9 @@ def main():
                                 "events_per_launch": {k: ev[k] / K for k in
                                                       ("histories", "facets", "collisions",
                                                        "census")},
-                                "valu_issue": issue_roofline(deck, nx, variant, name, ev, K),
+                                "valu_issue": issue_roofline(
+                                    deck, nx, variant, name, ev, K,
+                                    sum(r.stats.collide_passes for r in results) / world),
                                 "hbm": hbm_view(deck, nx, variant, name, ev, K, same)})
             if variant == 2:
                 kernels.append({"name": "tile sort (count, scan, place, chunks) + collision queue",
@@ -494,6 +544,36 @@ def main():
                 "roofline": roofline,
                 "kernels": kernels,
             }
+            out["exchange"] = {"ranks_summed_over": int(stats.exchange_ranks),
+                               "host_collectives_per_step": int(stats.host_collectives)}
+            if world > 1:
+                rec = one_rank_record(deck, nx, ntotal, K)
+                if rec is None:
+                    out["parity_vs_one_rank"] = {"recorded": False,
+                                                 "note": "no one-rank record for this workload and "
+                                                         "step count in profiles/one_rank_tally.json"}
+                else:
+                    out["parity_vs_one_rank"] = {
+                        "recorded": True,
+                        "event_counts_equal": all(tot[k] == rec["events"][k] for k in
+                                                  ("facets", "collisions", "census", "histories")),
+                        "global_tally_rel": abs(global_tally - rec["global_tally"]) /
+                        abs(rec["global_tally"]),
+                        "tolerance": 1e-12, "source": rec.get("source")}
+            elif args.record_one_rank:
+                path = one_rank_path()
+                table = {"entries": []}
+                if os.path.exists(path):
+                    with open(path) as f:
+                        table = json.load(f)
+                table["entries"] = [e for e in table["entries"] if (e["deck"], e["nx"], e["nparticles"],
+                                                                     e["steps"]) != (deck, nx, ntotal, K)]
+                table["entries"].append({"deck": deck, "nx": nx, "nparticles": ntotal, "steps": K,
+                                         "events": tot, "global_tally": global_tally,
+                                         "source": f"bench.py --gpus 1 --steps {K} --workload "
+                                                   f"{args.workload} --record-one-rank"})
+                with open(path, "w") as f:
+                    json.dump(table, f, indent=1)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"], oracle_run, n_sample = cpu_baseline(deck, nx, K,
                                                                          args.cpu_seconds, tmp)

@@ -102,6 +102,8 @@ struct State {
   hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   hipEvent_t ev_collected = nullptr; /* tiled variant: after the collision queue is built */
   hipEvent_t ev_exported = nullptr; /* tiled variant: after the write-back to the SoA arrays */
+  hipStream_t comm_stream = nullptr; /* several ranks: the exchange runs here, beside the write-back */
+  hipEvent_t ev_exchanged = nullptr;
   TableView tables;
   /* workspace of the tiled variant, grown on demand */
   neutral::TiledArgs tiled = {};
@@ -194,6 +196,8 @@ void ensure_scratch() {
   HIP_CHECK(hipEventCreate(&g.ev_streamed));
   HIP_CHECK(hipEventCreate(&g.ev_collected));
   HIP_CHECK(hipEventCreate(&g.ev_exported));
+  HIP_CHECK(hipEventCreateWithFlags(&g.ev_exchanged, hipEventDisableTiming));
+  HIP_CHECK(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
   g.scratch_device = dev;
 }
 
@@ -322,7 +326,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
       if (p) HIP_CHECK(hipFree(p));
     }
     const size_t n = (size_t)nparticles;
-    const size_t nb = (size_t)(tx * ty + 2);
+    const size_t nb = (size_t)(tx * ty * 4 + 2); /* (up to four reach classes per tile) */
     HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
@@ -340,7 +344,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     g.tiled_tiles = tx * ty;
   }
   /* the counting sort expects its histogram zeroed (it clears what it consumes) */
-  HIP_CHECK(hipMemsetAsync(t.tile_count, 0, sizeof(unsigned) * (size_t)(tx * ty + 2), g.stream));
+  HIP_CHECK(hipMemsetAsync(t.tile_count, 0, sizeof(unsigned) * (size_t)(tx * ty * 4 + 2), g.stream));
   if (max_chunks > g.tiled_chunks) {
     if (t.chunks) HIP_CHECK(hipFree(t.chunks));
     HIP_CHECK(hipMalloc((void**)&t.chunks, sizeof(uint4) * (size_t)max_chunks));
@@ -355,6 +359,25 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   t.tiles_x = tx;
   t.tiles_y = ty;
   t.ntiles = tx * ty;
+  /* Sparse problems (about a workgroup's worth of particles per tile and pass, or fewer)
+   * also sort by reach class inside a tile (neutral_history.h: reach_class); where tiles hold
+   * tens of thousands, lanes are refilled from the chunk and the order inside it does not
+   * matter.  NEUTRAL_REACH_CLASSES=1|4 overrides. */
+  {
+    const long long per_tile = (long long)nparticles_now / (tx * ty > 0 ? tx * ty : 1);
+    /* (and only while the buckets still fit the sort's LDS histogram: 8 192) */
+    int classes = (per_tile < 8192 && (long long)tx * ty * 4 + 1 <= 8192) ? 4 : 1;
+    const char* force = getenv("NEUTRAL_REACH_CLASSES");
+    if (force && (atoi(force) == 1 || atoi(force) == 4)) {
+      classes = atoi(force);
+    }
+    if (classes != t.reach_classes && t.reach_classes != 0) {
+      sync_soa();
+      drop_records(); /* (the summaries' class field changes meaning) */
+    }
+    t.reach_classes = classes;
+    t.nsort = t.ntiles * classes;
+  }
   t.max_chunks = max_chunks;
 }
 
@@ -514,24 +537,32 @@ __global__ void add_step_tally_kernel(double* __restrict__ tally, const double* 
  * cleared again, so a step that needs more stream passes than were enqueued simply
  * exchanges what those add. */
 void exchange_step(const neutral::SolveArgs& a, double* tally, bool tiled) {
+  /* on a stream of its own, after the step's kernels (g.ev_stop) and BESIDE the write-back
+   * of the records that the caller enqueues next on its own stream; finish_exchange() joins */
+  hipStream_t xs = g.comm_stream;
+  HIP_CHECK(hipStreamWaitEvent(xs, g.ev_stop, 0));
   const size_t ncells = (size_t)a.nx * (size_t)a.ny;
-  hipLaunchKernelGGL(pack_step_words_kernel, dim3(1), dim3(64), 0, g.stream, g.d_counters, g.d_check,
+  hipLaunchKernelGGL(pack_step_words_kernel, dim3(1), dim3(64), 0, xs, g.d_counters, g.d_check,
                      tiled ? (const unsigned*)g.tiled.ctrl : (const unsigned*)nullptr, g.d_words);
   HIP_CHECK(hipGetLastError());
-  neutral::comm_allreduce_sum(g.d_words, (size_t)kStepWords, false, g.stream);
-  neutral::comm_allreduce_sum(a.tally, ncells, true, g.stream);
+  neutral::comm_allreduce_sum(g.d_words, (size_t)kStepWords, false, xs);
+  neutral::comm_allreduce_sum(a.tally, ncells, true, xs);
   hipLaunchKernelGGL(add_step_tally_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
-                     g.stream, tally, (const double*)a.tally, ncells);
+                     xs, tally, (const double*)a.tally, ncells);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemsetAsync(a.tally, 0, sizeof(double) * ncells, g.stream));
+  HIP_CHECK(hipMemsetAsync(a.tally, 0, sizeof(double) * ncells, xs));
   if (g.flux_tally) { /* the scalar-flux mesh travels the same way */
-    neutral::comm_allreduce_sum(a.flux_tally, ncells, true, g.stream);
+    neutral::comm_allreduce_sum(a.flux_tally, ncells, true, xs);
     hipLaunchKernelGGL(add_step_tally_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0,
-                       g.stream, g.flux_tally, (const double*)a.flux_tally, ncells);
+                       xs, g.flux_tally, (const double*)a.flux_tally, ncells);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemsetAsync(a.flux_tally, 0, sizeof(double) * ncells, g.stream));
+    HIP_CHECK(hipMemsetAsync(a.flux_tally, 0, sizeof(double) * ncells, xs));
   }
+  HIP_CHECK(hipEventRecord(g.ev_exchanged, xs));
 }
+
+/* the caller's stream goes on only when the exchange is done (the step buffers are reused) */
+void finish_exchange() { HIP_CHECK(hipStreamWaitEvent(g.stream, g.ev_exchanged, 0)); }
 
 /* Decomposed mesh, one round: this rank's emigrants (records of t.rec_out marked
  * kRecEmigrate) go to the ranks that own the cells they crossed into; what arrives
@@ -1035,6 +1066,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
     }
     HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+    if (exchange) {
+      exchange_step(a, energy_deposition_tally, tiled); /* (beside the write-back below) */
+    }
     if (pass_export && !decomposed) {
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
       HIP_CHECK(neutral::launch_export_records(
@@ -1044,7 +1078,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
 
     if (exchange) {
-      exchange_step(a, energy_deposition_tally, tiled);
+      finish_exchange();
       HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
     }
     /* the one wait of a steady-state step: counters, the pipeline's control words
@@ -1106,6 +1140,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, more, passes, nullptr,
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
+        if (exchange) {
+          exchange_step(a, energy_deposition_tally, tiled);
+        }
         if (pass_export && !decomposed) {
           HIP_CHECK(neutral::launch_export_records(
               g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, nullptr,
@@ -1113,7 +1150,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         }
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {
-          exchange_step(a, energy_deposition_tally, tiled);
+          finish_exchange();
           HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
         }
         HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));

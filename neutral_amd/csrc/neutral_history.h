@@ -61,6 +61,21 @@ struct History {
    * new cell's density, before the arithmetic of the crossing -- instead of reading all
    * four edges again at the next loop head (omp3/neutral.c:438-447 reads them per event) */
   double target_x, target_y;
+  /* ... and how they follow from the mesh: target = edge[target_ix] + target_adj with
+   * target_ix = cell + 1, target_adj = -0.0 for a history that moves up the axis (the cell's
+   * upper edge: e + -0.0 is e, bit for bit, whatever e is) and target_ix = cell, target_adj
+   * = -OPEN_BOUND_CORRECTION for one that moves down (omp3/neutral.c:442-447).  Both are
+   * fixed between two reflections, so a crossing is one 8-byte load and one addition per
+   * axis -- no direction test, no select. */
+  double target_adj_x, target_adj_y;
+  int target_ix, target_iy; /* indices into the edge arrays as the kernel sees them */
+  /* ... and where a crossing leads (omp3/neutral.c:333-369), also fixed between two
+   * reflections: the cell index moves by step (+1, -1; 0 for a direction cosine of exactly
+   * zero, which crosses nothing on that axis) unless the history is in the wall cell (the
+   * last one going up, cell 0 going down; -1, no cell, for step 0), where it reflects.
+   * Cells of a history lie inside the global mesh, so "is in the wall cell" is what the
+   * reference's cell >= last / cell <= 0 come to. */
+  int step_x, step_y, wall_x, wall_y;
   unsigned id; /* particle index in the SoA store; RNG key = pid_base + id (omp3/neutral.c:89) */
   unsigned counter;
   unsigned nevents; /* events of this history so far: watchdog only */
@@ -459,15 +474,45 @@ enum RecState : int {
   kRecEmigrate = 4,  /* crossed into another rank's part of the mesh: waits to be sent */
   kRecGone = 5,      /* sent: the slot is empty (dropped at the next sort) */
 };
-constexpr unsigned kSummaryTileMask = (1u << (32 - kRecStateBits)) - 1u;
+constexpr int kReachBits = 2;
+constexpr unsigned kSummaryTileMask = (1u << (32 - kRecStateBits - kReachBits)) - 1u;
 
-/* record summary: state in the top three bits, tile of the cell below (tiles of
- * 1 << tile_shift cells per edge: the tiled variant picks 16..128 per problem).  An
- * emigrant's cell lies outside the local mesh: its tile field is not used. */
+/* record summary: state in the top three bits, then the history's reach class (below),
+ * then the tile of the cell (tiles of 1 << tile_shift cells per edge: the tiled variant
+ * picks 16..128 per problem).  An emigrant's cell lies outside the local mesh: its tile
+ * field is not used. */
 __device__ __forceinline__ unsigned slot_summary(int state, int cellx, int celly, int tiles_x,
-                                                 int tile_shift) {
+                                                 int tile_shift, unsigned reach = 0u) {
   return ((unsigned)state << (32 - kRecStateBits)) |
+         (reach << (32 - kRecStateBits - kReachBits)) |
          ((unsigned)((celly >> tile_shift) * tiles_x + (cellx >> tile_shift)) & kSummaryTileMask);
+}
+__device__ __forceinline__ unsigned summary_reach(unsigned summary) {
+  return (summary >> (32 - kRecStateBits - kReachBits)) & ((1u << kReachBits) - 1u);
+}
+
+/* How many facets a history will cross under the tally window of the tile it is in, in
+ * four classes (quarters of twice the window edge).  Sparse problems sort by it INSIDE a
+ * tile, so that the 64 histories a wave streams together are about equally long: a wave
+ * lasts as long as its longest history, and where a workgroup gets one particle per lane
+ * (the reference's decks as shipped: a thousand particles per tile and pass) nothing
+ * refills the lanes that finish early.  An estimate (straight flight to the window's
+ * edge); it orders work and changes no result. */
+__device__ __forceinline__ unsigned reach_class(double omega_x, double omega_y, int local_cellx,
+                                                int local_celly, int tile_shift, int window_cells,
+                                                double cells_per_x, double cells_per_y) {
+  const int tile = 1 << tile_shift;
+  const int margin = (window_cells - tile) >> 1;
+  const int fx = local_cellx & (tile - 1);
+  const int fy = local_celly & (tile - 1);
+  const double to_edge_x = (double)((omega_x >= 0.0) ? (tile - fx + margin) : (fx + 1 + margin));
+  const double to_edge_y = (double)((omega_y >= 0.0) ? (tile - fy + margin) : (fy + 1 + margin));
+  const double rate_x = fabs(omega_x) * cells_per_x; /* cells crossed per unit of path, per axis */
+  const double rate_y = fabs(omega_y) * cells_per_y;
+  const double path = fmin(to_edge_x / rate_x, to_edge_y / rate_y); /* (x / 0 = inf: the other axis) */
+  const double facets = path * (rate_x + rate_y);
+  const int cls = (int)(facets * (2.0 / (double)window_cells));
+  return (unsigned)((cls < 0) ? 0 : ((cls > 3) ? 3 : cls));
 }
 __device__ __forceinline__ int summary_state(unsigned summary) {
   return (int)(summary >> (32 - kRecStateBits));
@@ -615,11 +660,41 @@ __device__ __forceinline__ void decide_carried(History& h) {
   h.ev = running ? h.ev : (int)kEvEnd;
 }
 
+/* the facet loop's own loop head: does the history cross another facet?  The same
+ * comparisons as decide_carried() without the selects that name the event and its
+ * distance -- a history that does NOT go on leaves the loop, and decide_carried() names
+ * its event there, once, from the same state (same operands, same bits). */
+/* (h.distance / h.x_facet: the distance to the next facet, worked out by cross_facet while
+ * the new cell's density was still on its way) */
+__device__ __forceinline__ bool next_is_facet(History& h) {
+  const double distance_to_facet = h.distance;
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  const bool collides = (distance_to_collision < distance_to_facet) &
+                        (distance_to_collision < distance_to_census);
+  const bool crosses = (distance_to_facet < distance_to_census);
+  return (h.dt_to_census > 0.0) & crosses & !collides;
+}
+
+/* which edges the history aims at on each axis (History::target_ix ...), from its direction */
+__device__ __forceinline__ void aim_targets(History& h, const SolveArgs& a) {
+  const bool up_x = (h.omega_x >= 0.0); /* omp3/neutral.c:438-447 */
+  const bool up_y = (h.omega_y >= 0.0);
+  h.target_ix = h.cellx - a.x_off + a.pad + (up_x ? 1 : 0);
+  h.target_iy = h.celly - a.y_off + a.pad + (up_y ? 1 : 0);
+  h.target_adj_x = up_x ? -0.0 : -kOpenBoundCorrection;
+  h.target_adj_y = up_y ? -0.0 : -kOpenBoundCorrection;
+  h.step_x = (h.omega_x > 0.0) ? 1 : ((h.omega_x < 0.0) ? -1 : 0);
+  h.step_y = (h.omega_y > 0.0) ? 1 : ((h.omega_y < 0.0) ? -1 : 0);
+  h.wall_x = (h.omega_x > 0.0) ? a.global_nx - 1 : ((h.omega_x < 0.0) ? 0 : -1);
+  h.wall_y = (h.omega_y > 0.0) ? a.global_ny - 1 : ((h.omega_y < 0.0) ? 0 : -1);
+}
+
 /* the targets of the history's cell and direction, from the edge arrays */
 __device__ __forceinline__ void load_targets(History& h, const SolveArgs& a) {
-  const CellEdges e = load_edges(a, h.cellx, h.celly);
-  h.target_x = facet_target(h.omega_x, e.x_lo, e.x_hi);
-  h.target_y = facet_target(h.omega_y, e.y_lo, e.y_hi);
+  aim_targets(h, a);
+  h.target_x = *mesh_element(a.edgex, h.target_ix) + h.target_adj_x;
+  h.target_y = *mesh_element(a.edgey, h.target_iy) + h.target_adj_y;
 }
 
 template <bool kWatchdog = true>
@@ -750,19 +825,57 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
    * exec-mask bookkeeping per facet, and the stream kernel issues 0.7 scalar
    * instructions per vector instruction as it is */
   const bool xf = (h.x_facet != 0);
-  const double omega = xf ? h.omega_x : h.omega_y;
-  const int cell = xf ? h.cellx : h.celly;
-  const int last = (xf ? a.global_nx : a.global_ny) - 1;
-  const bool forward = (omega > 0.0);
-  const bool backward = (omega < 0.0);
-  /* (& and | on purpose: && / || come out as exec-mask regions) */
-  const bool reflect = (forward & (cell >= last)) | (backward & (cell <= 0));
-  const int step = reflect ? 0 : (forward ? 1 : (backward ? -1 : 0));
-  const int ncellx = h.cellx + (xf ? step : 0);
-  const int ncelly = h.celly + (xf ? 0 : step);
+  bool reflect;
+  int ncellx, ncelly;
+  if (kCarryTargets) {
+    /* (History::step_x ...: the direction tests were made when the history last turned) */
+    reflect = xf ? (h.cellx == h.wall_x) : (h.celly == h.wall_y);
+    ncellx = h.cellx + ((xf & !reflect) ? h.step_x : 0);
+    ncelly = h.celly + ((!xf & !reflect) ? h.step_y : 0);
+  } else {
+    const double omega = xf ? h.omega_x : h.omega_y;
+    const int cell = xf ? h.cellx : h.celly;
+    const int last = (xf ? a.global_nx : a.global_ny) - 1;
+    const bool forward = (omega > 0.0);
+    const bool backward = (omega < 0.0);
+    /* (& and | on purpose: && / || come out as exec-mask regions) */
+    reflect = (forward & (cell >= last)) | (backward & (cell <= 0));
+    const int step = reflect ? 0 : (forward ? 1 : (backward ? -1 : 0));
+    ncellx = h.cellx + (xf ? step : 0);
+    ncelly = h.celly + (xf ? 0 : step);
+  }
+  /* (Loads come back in the order they were issued, so what is needed first is asked for
+   * first: the edges, then the density.)
+   * The edges the history aims at from the cell it will be in (two 8-byte loads issued
+   * here, consumed after the arithmetic below): the target indices move with the cell; a
+   * reflection leaves the cell where it is and turns the history round, which re-aims
+   * the targets below */
+  double edge_ahead_x = 0.0, edge_ahead_y = 0.0;
+  if (kCarryTargets) {
+    h.target_ix += ncellx - h.cellx;
+    h.target_iy += ncelly - h.celly;
+    int ex = h.target_ix;
+    int ey = h.target_iy;
+    if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
+      /* (the neighbour may be another rank's cell: any edge of ours; the history stops) */
+      ex = (ex < 0) ? 0 : ((ex > a.nx + 2 * a.pad) ? a.nx + 2 * a.pad : ex);
+      ey = (ey < 0) ? 0 : ((ey > a.ny + 2 * a.pad) ? a.ny + 2 * a.pad : ey);
+    }
+#if defined(NEUTRAL_EXP_NO_EDGE_LOADS)
+    /* timing experiment only (uniform meshes): the edges worked out, not loaded */
+    edge_ahead_x = (double)ex * (1.0 / (double)a.nx);
+    edge_ahead_y = (double)ey * (1.0 / (double)a.ny);
+#else
+    edge_ahead_x = *mesh_element(a.edgex, ex);
+    edge_ahead_y = *mesh_element(a.edgey, ey);
+#endif
+  }
 #if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
   const double new_density = h.local_density; /* timing experiment only (uniform decks) */
 #else
+  if (kCarryTargets) {
+    __builtin_amdgcn_sched_barrier(0); /* (the edge loads are issued by here) */
+  }
   int dens_x = ncellx - a.x_off;
   int dens_y = ncelly - a.y_off;
   if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
@@ -774,21 +887,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   }
   const double new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
 #endif
-  /* the edges of the cell the history will be in, on both axes (two 16-byte loads issued
-   * here, consumed after the arithmetic below; a reflection leaves the cell, hence them,
-   * unchanged) */
-  CellEdges ne{0.0, 0.0, 0.0, 0.0};
-  if (kCarryTargets) {
-    int ex = ncellx - a.x_off + a.pad;
-    int ey = ncelly - a.y_off + a.pad;
-    if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
-      ex = (ex < 0) ? 0 : ((ex >= a.nx + 2 * a.pad) ? a.nx + 2 * a.pad - 1 : ex);
-      ey = (ey < 0) ? 0 : ((ey >= a.ny + 2 * a.pad) ? a.ny + 2 * a.pad - 1 : ey);
-    }
-    const double* px = mesh_element(a.edgex, ex);
-    const double* py = mesh_element(a.edgey, ey);
-    ne = CellEdges{px[0], px[1], py[0], py[1]};
-  }
 
   const double distance_to_facet = h.distance;
   if (kCachedReciprocals) {
@@ -831,11 +929,24 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   const bool flip_x = reflect & xf;
   const bool flip_y = reflect & !xf;
   if (kCarryTargets) {
+    h.cellx = ncellx;
+    h.celly = ncelly;
     if (__ballot(reflect) != 0) { /* wave-uniform: most trips of the facet loop skip it */
       h.omega_x = flip_x ? -h.omega_x : h.omega_x;
       h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
       h.omega_y = flip_y ? -h.omega_y : h.omega_y;
       h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
+      if (reflect) {
+        /* turned round in the same cell: the other edge of it (a dependent load, here only) */
+        aim_targets(h, a);
+        double ex = *mesh_element(a.edgex, h.target_ix);
+        double ey = *mesh_element(a.edgey, h.target_iy);
+        /* (waited for here, inside the rare branch: the common path then knows how many
+         * loads are in flight where the paths join, and waits for the edges alone) */
+        asm volatile("" : "+v"(ex), "+v"(ey));
+        edge_ahead_x = ex;
+        edge_ahead_y = ey;
+      }
     }
   } else {
     h.omega_x = flip_x ? -h.omega_x : h.omega_x;
@@ -846,8 +957,14 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   h.cellx = ncellx;
   h.celly = ncelly;
   if (kCarryTargets) {
-    h.target_x = facet_target(h.omega_x, ne.x_lo, ne.x_hi);
-    h.target_y = facet_target(h.omega_y, ne.y_lo, ne.y_hi);
+    h.target_x = edge_ahead_x + h.target_adj_x;
+    h.target_y = edge_ahead_y + h.target_adj_y;
+    /* the next loop head's distance to the facet needs the edges, not the density: it is
+     * worked out here, ahead of the wait for the density below (the loads were issued in
+     * that order), and pinned there */
+    calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv, h.target_x, h.target_y,
+                             h.distance, h.x_facet);
+    asm volatile("" : "+v"(h.distance), "+v"(h.x_facet));
   }
 
   /* pin the two quotients above the wait for the density: left alone, the compiler

@@ -186,9 +186,9 @@ struct TiledArgs {
                               of the records first; decomposed stores keep id_out[slot]) */
   unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
                               the dead last; later passes: the migrants, into rec_out) */
-  unsigned* tile_count;    /* ntiles + 2: histogram of the counting sort (zero between uses) */
-  unsigned* tile_offset;   /* ntiles + 2: first sorted position of each bucket */
-  unsigned* tile_cursor;   /* ntiles + 2: next free position of each bucket during placement */
+  unsigned* tile_count;    /* nsort + 2: histogram of the counting sort (zero between uses) */
+  unsigned* tile_offset;   /* nsort + 2: first sorted position of each bucket */
+  unsigned* tile_cursor;   /* nsort + 2: next free position of each bucket during placement */
   uint4* chunks;           /* max_chunks: {begin, end, tile, windowed} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
@@ -201,6 +201,7 @@ struct TiledArgs {
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants,
                               passes used */
   int chunk_particles;     /* particles one workgroup takes at a time */
+  int refill_min;          /* stream kernel: empty lanes of a wave that trigger a refill */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */
   int allow_migrate;       /* 0 on the last permitted pass: finish with global atomics */
   double cells_per_x;      /* nx / mesh width, ny / mesh height: for the estimate of how */
@@ -210,6 +211,9 @@ struct TiledArgs {
   int tiles_x;
   int tiles_y;
   int ntiles;
+  int reach_classes;       /* 1, or 4: records are sorted by (tile, reach class) -- sparse
+                              problems, neutral_history.h: reach_class */
+  int nsort;               /* buckets of the counting sort: ntiles * reach_classes (+ the dead) */
   int max_chunks;
 };
 

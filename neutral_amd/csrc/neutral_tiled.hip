@@ -67,7 +67,12 @@ constexpr int kStreamBlock = NEUTRAL_STREAM_BLOCK; /* 16 waves share one window 
  * every workgroup gets several (the host picks the size from the particle
  * count: tiled_chunk_particles). */
 constexpr int kChunkParticlesMax = 32768;
-constexpr int kChunkParticlesMin = 4096;
+/* (the floor is one particle per lane of a workgroup: where tiles hold about that many per
+ * pass -- the reference's decks as shipped, a thousand particles per tile -- a chunk of a
+ * few thousand puts a whole tile, four histories per lane one after the other, on ONE
+ * workgroup: stream 4000^2 / 1e6 64.9 -> 53.9 ms, profiles/r03/sparse_knobs.log) */
+constexpr int kChunkParticlesMin = 1024;
+constexpr int kChunkParticlesFloor = 512; /* (what NEUTRAL_CHUNK_MIN may go down to) */
 /* empty lanes that trigger a refill.  With the facet loop as lean as it is now a
  * wave does best refilling (almost) as a whole: its particles come from one tile and
  * start together, so their loads and LDS atomics stay close, which is worth more than
@@ -137,12 +142,15 @@ constexpr unsigned kNoBucket = 0xFFFFFFFFu;
  * ones); in later passes everything else stays where it is */
 __device__ __forceinline__ unsigned sort_bucket(const TiledArgs& t, unsigned summary) {
   const int state = summary_state(summary);
+  /* (tile, reach class): the classes of a tile follow each other, shortest flights first) */
+  const unsigned live = (t.reach_classes > 1)
+                            ? summary_tile(summary) * (unsigned)t.reach_classes + summary_reach(summary)
+                            : summary_tile(summary);
   if (t.pass == 0) {
     /* (a slot whose particle was sent to another rank is not carried over at all) */
-    return (state == kRecGone) ? kNoBucket
-                               : (state != kRecDead) ? summary_tile(summary) : (unsigned)t.ntiles;
+    return (state == kRecGone) ? kNoBucket : (state != kRecDead) ? live : (unsigned)t.nsort;
   }
-  return (state == kRecMigrate) ? summary_tile(summary) : kNoBucket;
+  return (state == kRecMigrate) ? live : kNoBucket;
 }
 
 /* the summaries a pass sorts: last step's in pass 0, this step's (written by the
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, Til
   if (pass_is_empty(t)) {
     return;
   }
-  const int nbins = t.ntiles + 1;
+  const int nbins = t.nsort + 1;
   const bool in_lds = nbins <= kSortLdsBins;
   if (in_lds) {
     for (int b = threadIdx.x; b < nbins; b += kSortBlock) {
@@ -176,10 +184,22 @@ __global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, Til
 #pragma unroll 4
   for (int k = 0; k < kSortItems; ++k) {
     const long long i = base + (long long)k * kSortBlock + threadIdx.x;
-    if (i < t.sort_end) {
-      const unsigned b = sort_bucket(t, info[i]);
+    const unsigned b = (i < t.sort_end) ? sort_bucket(t, info[i]) : kNoBucket;
+    if (in_lds) {
       if (b != kNoBucket) {
-        atomicAdd(in_lds ? &s_bins[b] : &t.tile_count[b], 1u);
+        atomicAdd(&s_bins[b], 1u);
+      }
+    } else {
+      /* (more buckets than fit the LDS: one global atomic per record -- except for the dead,
+       * who all share ONE bucket: a wave counts its own and adds once, or a step in which
+       * most particles are dead queues millions of adds on a single word) */
+      const bool is_dead = (b == (unsigned)t.nsort);
+      const unsigned long long m_dead = __ballot(is_dead);
+      if (b != kNoBucket && !is_dead) {
+        atomicAdd(&t.tile_count[b], 1u);
+      }
+      if (m_dead != 0 && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m_dead) - 1u) {
+        atomicAdd(&t.tile_count[t.nsort], (unsigned)__popcll(m_dead));
       }
     }
   }
@@ -195,18 +215,18 @@ __global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, Til
 }
 
 /* single workgroup: tile_offset[k] = first sorted position of bucket k, for
- * k = 0..ntiles+1 (empty tiles included); tile_cursor = the same, consumed by the
+ * k = 0..nsort+1 (empty tiles included); tile_cursor = the same, consumed by the
  * placement; tile_count is cleared for the next pass */
 __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
   __shared__ unsigned s_part[1024];
   const int tid = threadIdx.x;
-  const int n = t.ntiles + 2;
+  const int n = t.nsort + 2;
   const int per = (n + 1023) / 1024;
   const int lo = (tid * per < n) ? tid * per : n;
   const int hi = (lo + per < n) ? lo + per : n;
   unsigned sum = 0;
   for (int i = lo; i < hi; ++i) {
-    sum += (i <= t.ntiles) ? t.tile_count[i] : 0u;
+    sum += (i <= t.nsort) ? t.tile_count[i] : 0u;
   }
   s_part[tid] = sum;
   __syncthreads();
@@ -221,10 +241,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
   }
   unsigned run = s_part[tid] - sum; /* exclusive */
   for (int i = lo; i < hi; ++i) {
-    const unsigned c = (i <= t.ntiles) ? t.tile_count[i] : 0u;
+    const unsigned c = (i <= t.nsort) ? t.tile_count[i] : 0u;
     t.tile_offset[i] = run;
     t.tile_cursor[i] = run;
-    if (i <= t.ntiles) {
+    if (i <= t.nsort) {
       t.tile_count[i] = 0;
     }
     run += c;
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
   if (pass_is_empty(t)) {
     return;
   }
-  const int nbins = t.ntiles + 1;
+  const int nbins = t.nsort + 1;
   const bool in_lds = nbins <= kSortLdsBins;
   unsigned* s_rank = s_bins;
   unsigned* s_base = s_bins + nbins;
@@ -257,8 +277,20 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
   if (!in_lds) {
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
+      /* (the dead share one bucket: a wave reserves its records' places with one atomic) */
+      const bool is_dead = (bucket[k] == (unsigned)t.nsort);
+      const unsigned long long m_dead = __ballot(is_dead);
+      unsigned dead_base = 0;
+      if (m_dead != 0) {
+        const unsigned leader = (unsigned)__ffsll((long long)m_dead) - 1u;
+        if ((threadIdx.x & 63) == leader) {
+          dead_base = atomicAdd(&t.tile_cursor[t.nsort], (unsigned)__popcll(m_dead));
+        }
+        dead_base = __shfl(dead_base, (int)leader, 64);
+      }
       if (bucket[k] != kNoBucket) {
-        const unsigned pos = atomicAdd(&t.tile_cursor[bucket[k]], 1u);
+        const unsigned pos = is_dead ? dead_base + (unsigned)lane_rank(m_dead)
+                                     : atomicAdd(&t.tile_cursor[bucket[k]], 1u);
         t.order[pos] = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
       }
     }
@@ -299,7 +331,7 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
   if (a.abort_flag && *a.abort_flag) {
     return; /* (an abandoned attempt leaves slot_of_id as the last finished step made it) */
   }
-  const unsigned first_inactive = t.tile_offset[t.ntiles];
+  const unsigned first_inactive = t.tile_offset[t.nsort];
   const unsigned u = blockIdx.x * kSortBlock + threadIdx.x;
   const unsigned ncarried = (unsigned)t.sort_end - first_inactive;
   if (u < ncarried) {
@@ -464,7 +496,8 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   __shared__ unsigned s_chunks[1024];
   const int tid = threadIdx.x;
-  const unsigned nactive = t.tile_offset[t.ntiles];
+  const unsigned nactive = t.tile_offset[t.nsort];
+  const int classes = t.reach_classes; /* (a tile's buckets follow each other) */
   long long per = (t.ntiles + 1023) / 1024;
   if (nactive > 0) {
     const long long per_sparse =
@@ -506,8 +539,8 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
       }
     };
     for (int i = lo; i < hi; ++i) {
-      const unsigned begin = t.tile_offset[i];
-      const unsigned end = t.tile_offset[i + 1];
+      const unsigned begin = t.tile_offset[i * classes];
+      const unsigned end = t.tile_offset[(i + 1) * classes];
       if (end - begin >= (unsigned)t.window_min_particles) {
         emit(run_begin, run_end, 0u, 0u);
         run_begin = run_end = end;
@@ -544,7 +577,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
     if (t.pass == 0) {
       t.ctrl[kCtrlPassesUsed] = 1;
       t.ctrl[kCtrlEmigrants] = 0;
-      t.ctrl[kCtrlFirstInactive] = t.tile_offset[t.ntiles];
+      t.ctrl[kCtrlFirstInactive] = t.tile_offset[t.nsort];
     } else if (nactive > 0) {
       t.ctrl[kCtrlPassesUsed] = (unsigned)t.pass + 1u;
     }
@@ -682,7 +715,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       int park = kRecIdle; /* kRecCollide / kRecMigrate: this lane hands its history on */
       bool did_census = false;
-      if (n_empty >= kStreamRefillMin || n_stream == 0) {
+      if (n_empty >= t.refill_min || n_stream == 0) {
         /* REFILL: take n_empty ids of the chunk */
         int base = 0;
         if ((threadIdx.x & 63) == 0) {
@@ -777,19 +810,26 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                 break;
               }
             }
-            if (kCarryTargets) {
-              decide_carried(h);
-            } else {
-              decide<false>(h, a);
-            }
             /* (selects, then one exit test: the nested form costs ~15 more scalar
              * exec-mask instructions per facet) */
-            const bool goes_on = (h.ev == kEvFacet);
-            park = (h.ev == kEvCollision) ? (int)kRecCollide : park;
+            bool goes_on;
+            if (kCarryTargets) {
+              goes_on = next_is_facet(h); /* (what ends the flight is named below, once) */
+            } else {
+              decide<false>(h, a);
+              goes_on = (h.ev == kEvFacet);
+              park = (h.ev == kEvCollision) ? (int)kRecCollide : park;
+            }
             crossed = goes_on ? crossed : rep + 1;
             if (!goes_on) {
               break;
             }
+          }
+          if (kCarryTargets) {
+            /* the event that ended the run of crossings (or another facet), from the
+             * state the loop left: the comparisons next_is_facet() made, with names */
+            decide_carried(h);
+            park = (park == kRecIdle && h.ev == kEvCollision) ? (int)kRecCollide : park;
           }
           /* facets are counted, and the event watchdog applied, once per pass (the
            * loop counter is scalar: per facet they cost three vector and half a
@@ -815,8 +855,13 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           store_record(h, a, t.rec_out[pid], kRecIdle);
-          t.info_out[pid] = slot_summary(kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
-                                         t.tile_shift);
+          /* (its reach class: where the next step's pass 0 puts it inside its tile) */
+          t.info_out[pid] = slot_summary(
+              kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
+              t.reach_classes > 1 ? reach_class(h.omega_x, h.omega_y, h.cellx - a.x_off,
+                                                h.celly - a.y_off, t.tile_shift, kW, t.cells_per_x,
+                                                t.cells_per_y)
+                                  : 0u);
           if (a.export_view) {
             /* the interface's arrays stay current (pointers fetched here, not kept
              * in registers through the facet loop) */
@@ -831,8 +876,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       /* histories handed on: the record carries the state; migrants are counted */
       if (park != kRecIdle) {
         store_record(h, a, t.rec_out[pid], park);
-        t.info_out[pid] = slot_summary(park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x,
-                                       t.tile_shift);
+        t.info_out[pid] = slot_summary(
+            park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
+            (t.reach_classes > 1 && park == kRecMigrate)
+                ? reach_class(h.omega_x, h.omega_y, h.cellx - a.x_off, h.celly - a.y_off,
+                              t.tile_shift, kW, t.cells_per_x, t.cells_per_y)
+                : 0u);
         has = false;
       }
       w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
@@ -1099,7 +1148,12 @@ int tiled_chunk_particles(int nparticles, int compute_units) {
 #endif
   long long c = (long long)nparticles / ((long long)compute_units * NEUTRAL_CHUNKS_PER_WG);
   if (c > kChunkParticlesMax) c = kChunkParticlesMax;
-  if (c < kChunkParticlesMin) c = kChunkParticlesMin;
+  int floor_c = kChunkParticlesMin;
+  const char* force = getenv("NEUTRAL_CHUNK_MIN"); /* experiment knob */
+  if (force && atoi(force) >= kChunkParticlesFloor) {
+    floor_c = atoi(force);
+  }
+  if (c < floor_c) c = floor_c;
   return (int)c;
 }
 
@@ -1145,7 +1199,7 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
   *tiles_x = (nx + tile - 1) / tile;
   *tiles_y = (ny + tile - 1) / tile;
   /* every tile can end with one partial chunk */
-  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesMin + 1;
+  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesFloor + 1;
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
@@ -1189,7 +1243,7 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
   /* (the graveyard beyond sort_end takes no part; a grid of one block when nothing does) */
   const int grid_n = (a.nparticles + kSortBlock - 1) / kSortBlock;
   const int grid_seg = t.sort_end > 0 ? (t.sort_end + kSortSegment - 1) / kSortSegment : 1;
-  const int nbins = t.ntiles + 1;
+  const int nbins = t.nsort + 1;
   const size_t lds_bins = (nbins <= kSortLdsBins) ? sizeof(unsigned) * (size_t)nbins : 0;
   hipLaunchKernelGGL(tile_count_kernel, dim3(grid_seg), dim3(kSortBlock), lds_bins, stream, a, t);
   hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, t);
@@ -1258,6 +1312,13 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
+  t.refill_min = kStreamRefillMin;
+  {
+    const char* force = getenv("NEUTRAL_STREAM_REFILL"); /* experiment knob */
+    if (force && atoi(force) >= 1 && atoi(force) <= 64) {
+      t.refill_min = atoi(force);
+    }
+  }
   const size_t lds = tiled_lds_bytes(a);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -14,8 +14,10 @@ from conftest import ROOT, gpu_available
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
 
 
-def _bench(extra, nproc):
+def _bench(extra, nproc, record=None):
     env = dict(os.environ)
+    if record:
+        env["NEUTRAL_ONE_RANK_RECORD"] = record
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     base = [sys.executable]
     if nproc > 1:
@@ -30,9 +32,15 @@ def _bench(extra, nproc):
     return json.loads(lines[0])
 
 
-def test_two_rank_bench_equals_one_rank():
-    one = _bench([], 1)
-    two = _bench(["--comm", "host", "--share-device"], 2)
+def test_two_rank_bench_equals_one_rank(tmp_path):
+    record = str(tmp_path / "one_rank.json")
+    one = _bench(["--record-one-rank"], 1, record)
+    two = _bench(["--comm", "host", "--share-device"], 2, record)
+    # the N > 1 line checks itself against the one-rank record and says what its exchange did
+    assert two["parity_vs_one_rank"]["recorded"] and two["parity_vs_one_rank"]["event_counts_equal"]
+    assert two["parity_vs_one_rank"]["global_tally_rel"] <= 1e-12
+    assert two["exchange"] == {"ranks_summed_over": 2, "host_collectives_per_step": 0}
+    assert one["exchange"]["ranks_summed_over"] == 1
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert "host" in two["config"]["tally_exchange"]
     assert two["events"] == one["events"]                      # exact event totals

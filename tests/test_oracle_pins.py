@@ -151,8 +151,11 @@ DEFAULT_DECKS = ["stream", "csp", pytest.param("scatter", marks=[pytest.mark.ful
 def test_reference_held__known_answers_default_decks(make_problem, cs, name):
     """problems/neutral.tests:1-3 at the decks' default sizes (4000^2 cells; 1e6, 1e6,
     1e7 particles; 1, 10, 2 iterations), the reference's own tolerance."""
-    tally, _, _ = _default_deck_run(make_problem, cs, name)
+    tally, facets, collisions = _default_deck_run(make_problem, cs, name)
     expected = decks.KNOWN_ANSWERS[name]
+    # (shown by `make test-cpu` / `make pin-kats`: oracle/pins/full_kats.log)
+    print(f"{name} as shipped: facets={facets} collisions={collisions} tally={tally:.15e} "
+          f"expected={expected:.12e} rel={abs(tally - expected) / expected:.2e}")
     assert abs(tally - expected) / expected < decks.VALIDATE_TOLERANCE
 
 

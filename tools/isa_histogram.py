@@ -115,10 +115,23 @@ def hot_loop(items, marker, min_marker):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("target", choices=sorted(TARGETS))
+    ap.add_argument("target", choices=sorted(TARGETS) + ["mix"])
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--dump", action="store_true", help="print the loop's instructions")
     args = ap.parse_args()
+    if args.target == "mix":
+        # profiles/isa_mix.json: what bench.py prices the issue roofline with
+        import subprocess
+        import sys
+        mix = {t: json.loads(subprocess.check_output([sys.executable, os.path.abspath(__file__), t,
+                                                      "--json"])) for t in sorted(TARGETS)}
+        with open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w") as f:
+            json.dump(mix, f, indent=1)
+        for t, m in mix.items():
+            print(f"{t}: {m['valu_instructions']} VALU per trip, {m['issue_cycles_per_trip']:.0f} cycles, "
+                  f"mean {m['mean_cycles_per_valu']:.3f} ({m['mean_cycles_per_valu_low']:.3f}-"
+                  f"{m['mean_cycles_per_valu_high']:.3f})")
+        return
     fname, symbol, marker, min_marker = TARGETS[args.target]
     items = parse(function_body(os.path.join(BUILD, fname), symbol))
     a, b = hot_loop(items, marker, min_marker)
@@ -140,10 +153,18 @@ def main():
         cycles += n * c
         by_how[how] += n * c
     nvalu = sum(valu.values())
+    # what the family-priced opcodes could move: all of them at the cheapest cost measured
+    # (a two-operand 32-bit op) or at the dearest full-rate one
+    fam = sum(r["count"] for r in rows if r["priced"] == "family")
+    fam_cycles = sum(r["count"] * r["cycles_each"] for r in rows if r["priced"] == "family")
+    lo_cycles = cycles - fam_cycles + fam * min(costs.get("v_xor_b32", 2.0), 2.0)
+    hi_cycles = cycles - fam_cycles + fam * max(costs.get("v_mad_u64_u32", 4.4), 4.4)
     out = {"target": args.target, "symbol": symbol,
            "loop": {"first_label": span[0][0], "instructions": sum(1 for _, op, _ in span if op)},
            "valu_instructions": nvalu, "salu_instructions": salu, "memory_instructions": dict(mem),
-           "issue_cycles": cycles, "mean_cycles_per_valu": cycles / max(nvalu, 1),
+           "issue_cycles_per_trip": cycles, "mean_cycles_per_valu": cycles / max(nvalu, 1),
+           "mean_cycles_per_valu_low": lo_cycles / max(nvalu, 1),
+           "mean_cycles_per_valu_high": hi_cycles / max(nvalu, 1),
            "cycles_priced_by_measurement": by_how["measured"] / max(cycles, 1e-9),
            "opcodes": rows}
     if args.json:
