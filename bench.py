@@ -67,6 +67,11 @@ WORKLOADS = {
     "stream": ("stream", 400, 10_000_000, 1),
     "scatter": ("scatter", 400, 100_000_000, 2),
     "split": ("split", 800, 100_000_000, 1),
+    # the reference's decks as shipped (problems/*.params: 4000^2 cells)
+    "stream4000": ("stream", 4000, 1_000_000, 1),
+    "csp4000": ("csp", 4000, 1_000_000, 10),
+    "scatter4000": ("scatter", 4000, 10_000_000, 2),
+    "split4000": ("split", 4000, 1_000_000, 1),
 }
 
 
@@ -523,8 +528,10 @@ def main():
                 "dtype": "f64",
                 "data": "synthetic",
                 "config": {"workload": f"problems/{deck}.params at nx=ny={nx}, {ntotal} particles, "
-                                       f"{K} timesteps (BASELINE.json: the metric is quoted on csp "
-                                       "400x400, 1e8 particles)",
+                                       f"{K} timesteps" +
+                                       (" (BASELINE.json: the metric is quoted on csp 400x400, 1e8 "
+                                        "particles)" if args.workload == "csp" else
+                                        f" (--workload {args.workload})"),
                            "deck": deck, "nx": nx, "ny": nx, "nparticles": ntotal,
                            "timesteps": K, "parallelism": f"particle-shard x{world}",
                            "kernel_variant": variant,

@@ -309,6 +309,17 @@ __device__ __forceinline__ double sqrt_of_physical(double x) {
 __device__ __forceinline__ double refined_reciprocal(double b);                           /* below */
 __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, double r); /* below */
 
+/* fma(r, z, c) as ONE three-operand instruction (c stays where it is) */
+__device__ __forceinline__ double horner_step(double r, double z, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NEUTRAL_NO_HORNER_ASM)
+  double out;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(r), "v"(z), "v"(c));
+  return out;
+#else
+  return __builtin_fma(r, z, c);
+#endif
+}
+
 __device__ __forceinline__ double log_core(double x, int k_scaled) {
   double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
   int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
@@ -321,16 +332,19 @@ __device__ __forceinline__ double log_core(double x, int k_scaled) {
   const double denom = 2.0 + f;
   const double s = quotient_by_reciprocal(f, denom, refined_reciprocal(denom));
   const double z = s * s;
+  /* (Horner steps through horner_step(): left to itself the compiler turns r = fma(r, z, c)
+   * into v_mov_b64 tmp, c; v_fmac_f64 tmp, r, z -- a 4-cycle register copy per step in a
+   * kernel that is bound by vector issue -- where v_fma_f64 takes c as a third operand) */
   double r = 2.0 / 21.0;
-  r = __builtin_fma(r, z, 2.0 / 19.0);
-  r = __builtin_fma(r, z, 2.0 / 17.0);
-  r = __builtin_fma(r, z, 2.0 / 15.0);
-  r = __builtin_fma(r, z, 2.0 / 13.0);
-  r = __builtin_fma(r, z, 2.0 / 11.0);
-  r = __builtin_fma(r, z, 2.0 / 9.0);
-  r = __builtin_fma(r, z, 2.0 / 7.0);
-  r = __builtin_fma(r, z, 2.0 / 5.0);
-  r = __builtin_fma(r, z, 2.0 / 3.0);
+  r = horner_step(r, z, 2.0 / 19.0);
+  r = horner_step(r, z, 2.0 / 17.0);
+  r = horner_step(r, z, 2.0 / 15.0);
+  r = horner_step(r, z, 2.0 / 13.0);
+  r = horner_step(r, z, 2.0 / 11.0);
+  r = horner_step(r, z, 2.0 / 9.0);
+  r = horner_step(r, z, 2.0 / 7.0);
+  r = horner_step(r, z, 2.0 / 5.0);
+  r = horner_step(r, z, 2.0 / 3.0);
   r = r * z;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)k;

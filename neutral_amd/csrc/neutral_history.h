@@ -542,7 +542,15 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.celly = h.celly;
   o.id = h.id;
   o.dead = record_word(state, h.counter);
-  r = o;
+  /* (the 80 bytes a record holds, as five 16-byte stores: not the padding of an
+   * over-aligned record) */
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u* src = (const v4u*)&o;
+  v4u* dst = (v4u*)&r;
+#pragma unroll
+  for (int k = 0; k < kParticleRecBytes / 16; ++k) {
+    dst[k] = src[k];
+  }
 }
 
 /* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */

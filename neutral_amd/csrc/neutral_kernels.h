@@ -32,13 +32,19 @@ struct ParticleView {
  * Sorted-by-tile access is random per particle, and a random 80-B record costs
  * two 64-B sectors where the SoA store costs eleven; the records are kept in
  * tile order from step to step and carry the particle id (the RNG key). */
-struct alignas(16) ParticleRec {
+/* (experiment switch NEUTRAL_REC_ALIGN=128: one record per 128-byte line) */
+#ifndef NEUTRAL_REC_ALIGN
+#define NEUTRAL_REC_ALIGN 16
+#endif
+struct alignas(NEUTRAL_REC_ALIGN) ParticleRec {
   double x, y, omega_x, omega_y, energy, weight, dt_to_census, mfp_to_collision;
   int cellx, celly;
   unsigned id; /* index in the SoA store = global id - pid_base */
   int dead;
 };
-static_assert(sizeof(ParticleRec) == 80, "ParticleRec must stay 80 bytes");
+constexpr int kParticleRecBytes = 80; /* what a record holds, whatever its alignment pads it to */
+static_assert(sizeof(ParticleRec) == (NEUTRAL_REC_ALIGN > 80 ? NEUTRAL_REC_ALIGN : 80),
+              "ParticleRec holds 80 bytes");
 
 /* What a history suspended MID-CHAIN by the collision stage's time slicing needs
  * beyond its record: the RNG counter, the deposition not yet tallied
