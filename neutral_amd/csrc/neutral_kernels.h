@@ -219,6 +219,7 @@ struct TiledArgs {
   int ntiles;
   int reach_classes;       /* 1, or 4: records are sorted by (tile, reach class) -- sparse
                               problems, neutral_history.h: reach_class */
+  int reach_longest_first; /* the classes of a tile in descending order (default) */
   int nsort;               /* buckets of the counting sort: ntiles * reach_classes (+ the dead) */
   int max_chunks;
 };

@@ -143,8 +143,12 @@ constexpr unsigned kNoBucket = 0xFFFFFFFFu;
 __device__ __forceinline__ unsigned sort_bucket(const TiledArgs& t, unsigned summary) {
   const int state = summary_state(summary);
   /* (tile, reach class): the classes of a tile follow each other, shortest flights first) */
+  /* (longest flights first: the chunks of a tile are handed out in this order, and the
+   * long ones are the ones worth starting early -- stream 4000^2 / 1e6 49.5 -> 47.9 ms;
+   * NEUTRAL_REACH_SHORTEST_FIRST is the A/B) */
+  const unsigned cls = t.reach_longest_first ? 3u - summary_reach(summary) : summary_reach(summary);
   const unsigned live = (t.reach_classes > 1)
-                            ? summary_tile(summary) * (unsigned)t.reach_classes + summary_reach(summary)
+                            ? summary_tile(summary) * (unsigned)t.reach_classes + cls
                             : summary_tile(summary);
   if (t.pass == 0) {
     /* (a slot whose particle was sent to another rank is not carried over at all) */
@@ -1190,7 +1194,9 @@ int tiled_window_min_particles(int tile_shift) {
   if (force) {
     return atoi(force);
   }
-  return 2048 >> (tile_shift - 4);
+  /* (128-cell tiles -- the sparsest problems -- from 64 particles on: their histories
+   * cross the whole window, a hundred facets and more each) */
+  return (tile_shift >= 7) ? 64 : (2048 >> (tile_shift - 4));
 }
 
 void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x, int* tiles_y,
@@ -1312,6 +1318,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
+  t.reach_longest_first = getenv("NEUTRAL_REACH_SHORTEST_FIRST") ? 0 : 1; /* (experiment knob) */
   t.refill_min = kStreamRefillMin;
   {
     const char* force = getenv("NEUTRAL_STREAM_REFILL"); /* experiment knob */

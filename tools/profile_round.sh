@@ -1,27 +1,39 @@
 #!/bin/bash
-# End-of-round evidence: default bench (JSON, kernel-trace stats, PMC passes -> per-event
-# coefficients), all BASELINE configurations per variant, the reference's decks as shipped,
-# the bench workload's multi-GPU shares on one GPU, per-kernel traces and SQ counters of the
-# other decks.
-#   bash tools/profile_round.sh <tag>      (on the GPU box; results under gpurun_out/<tag>/)
-R=$GRAFT_REPO_ROOT; tag=${1:-rXX}; out=$R/gpurun_out/$tag; mkdir -p $out
-bash $R/tools/profile_bench.sh $tag
-echo "profile_bench done" >> $out/progress.log
-bash $R/tools/baseline_configs.sh > $out/baseline_configs.log 2>&1
-echo "baseline_configs done" >> $out/progress.log
+# End-of-round evidence, in parts that each fit one gpurun call (results under gpurun_out/<tag>/):
+#   bash tools/profile_round.sh <tag> headline   default bench (JSON, kernel-trace stats, PMC passes -> per-event
+#                                                coefficients, priced again), the driver-style run (--steps 20
+#                                                --warmup 5) that also records the one-rank tallies N > 1 runs check
+#   bash tools/profile_round.sh <tag> configs    light profile (bench line, kernel-trace stats, PMC coefficients)
+#                                                of the other BASELINE configurations
+#   bash tools/profile_round.sh <tag> shipped    the same for the reference's decks as shipped (4000^2)
+#   bash tools/profile_round.sh <tag> matrix     all BASELINE configurations per kernel variant, the shipped decks,
+#                                                the bench workload's multi-GPU shares on one GPU
+R=$GRAFT_REPO_ROOT; tag=${1:-rXX}; part=${2:-headline}; out=$R/gpurun_out/$tag; mkdir -p $out
 cd $R
-python tools/ablate.py matrix --run "stream 4000 1000000 1 2" --run "csp 4000 1000000 10 2" \
-  --run "scatter 4000 10000000 2 2" --run "split 4000 1000000 1 2" > $out/default_decks.log 2>&1
-NEUTRAL_EAGER_EXPORT=1 python tools/ablate.py matrix --run "stream 4000 1000000 1 2" \
-  --run "csp 4000 1000000 10 2" >> $out/default_decks.log 2>&1
-echo "default decks done" >> $out/progress.log
-bash tools/share_bench.sh $tag/share > $out/share_bench.log 2>&1
-echo "shares done" >> $out/progress.log
-for cfg in "stream 400 10000000 1" "scatter 400 20000000 1" "split 800 20000000 1"; do
-  set -- $cfg
-  bash $R/tools/ktrace.sh $1 $cfg 2 > $out/ktrace_$1.txt 2>&1
-  bash $R/tools/pmc.sh $1 $cfg 2 > $out/pmc_sq_$1.txt 2>&1
-  echo "$1 traces done" >> $out/progress.log
-done
-bash $R/tools/pmc.sh csp csp 400 20000000 10 2 > $out/pmc_sq_csp.txt 2>&1
-tail -4 $out/baseline_configs.log
+case $part in
+headline)
+  bash tools/profile_bench.sh $tag
+  python3 bench.py --steps 20 --warmup 5 --record-one-rank > $out/bench_driver_style.json 2> $out/bench_driver_style.err
+  python3 bench.py --steps 10 --warmup 1 --record-one-rank --no-cpu-baseline --no-lazy-leg > /dev/null 2>&1
+  tail -c 300 $out/bench_driver_style.json; echo
+  cp profiles/one_rank_tally.json $out/one_rank_tally.json
+  ;;
+configs)
+  bash tools/profile_bench.sh $tag/stream --light --workload stream --steps 10 --warmup 1
+  bash tools/profile_bench.sh $tag/scatter --light --workload scatter --steps 2 --warmup 0
+  bash tools/profile_bench.sh $tag/split --light --workload split --steps 1 --warmup 0
+  ;;
+shipped)
+  bash tools/profile_bench.sh $tag/stream4000 --light --workload stream4000 --steps 4 --warmup 1
+  bash tools/profile_bench.sh $tag/csp4000 --light --workload csp4000 --steps 10 --warmup 1
+  ;;
+matrix)
+  bash tools/baseline_configs.sh > $out/baseline_configs.log 2>&1
+  python tools/ablate.py matrix --run "stream 4000 1000000 1 2" --run "csp 4000 1000000 10 2" \
+    --run "scatter 4000 10000000 2 2" --run "split 4000 1000000 1 2" > $out/default_decks.log 2>&1
+  NEUTRAL_EAGER_EXPORT=1 python tools/ablate.py matrix --run "stream 4000 1000000 1 2" \
+    --run "csp 4000 1000000 10 2" >> $out/default_decks.log 2>&1
+  bash tools/share_bench.sh $tag/share > $out/share_bench.log 2>&1
+  tail -4 $out/baseline_configs.log; cat $out/default_decks.log | cut -c1-160; tail -5 $out/share_bench.log
+  ;;
+esac
