@@ -401,7 +401,10 @@ def main():
             with socket.socket() as sock:
                 sock.bind(("127.0.0.1", 0))
                 store.set("neutral_comm_port", str(sock.getsockname()[1]))
+            # the word this launch's ranks greet rank 0 with (host/comms_ranks.c)
+            store.set("neutral_comm_nonce", str(int.from_bytes(os.urandom(8), "little")))
         os.environ["NEUTRAL_COMM_PORT"] = store.get("neutral_comm_port").decode()
+        os.environ.setdefault("NEUTRAL_COMM_NONCE", store.get("neutral_comm_nonce").decode())
     # the rank layer of the library: TCP rendezvous of the ranks, then RCCL on this rank's
     # GPU with a time limit; a rank that cannot get RCCL up makes every rank stage the
     # exchange through the host instead (reported below)

@@ -27,6 +27,14 @@ shipped)
   bash tools/profile_bench.sh $tag/stream4000 --light --workload stream4000 --steps 4 --warmup 1
   bash tools/profile_bench.sh $tag/csp4000 --light --workload csp4000 --steps 10 --warmup 1
   ;;
+priced)
+  # every workload's bench line again, priced with the coefficients committed by the parts above
+  for w in "stream 10 1" "scatter 2 0" "split 1 0" "stream4000 4 1" "csp4000 10 1"; do
+    set -- $w
+    python3 bench.py --workload $1 --steps $2 --warmup $3 --no-cpu-baseline > $out/$1/bench_priced.json 2> $out/$1/bench_priced.err
+    tail -c 200 $out/$1/bench_priced.json; echo
+  done
+  ;;
 matrix)
   bash tools/baseline_configs.sh > $out/baseline_configs.log 2>&1
   python tools/ablate.py matrix --run "stream 4000 1000000 1 2" --run "csp 4000 1000000 10 2" \
