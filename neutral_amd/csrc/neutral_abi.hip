@@ -321,7 +321,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   if (grow) {
     void* old[] = {t.order,  t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor, t.rec_in,
                    t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out,
-                   t.slot_of_id};
+                   t.slot_of_id, t.tile_uniform};
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -340,6 +340,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_cursor, sizeof(unsigned) * nb));
+    HIP_CHECK(hipMalloc((void**)&t.tile_uniform, (size_t)(tx * ty + 1)));
+    HIP_CHECK(hipMemsetAsync(t.tile_uniform, 0, (size_t)(tx * ty + 1), g.stream));
     g.tiled_particles = nparticles;
     g.tiled_tiles = tx * ty;
   }

@@ -97,6 +97,8 @@ struct History {
 template <bool kWithFlux>
 struct GlobalTallyT {
   static constexpr bool kFlux = kWithFlux;
+  static constexpr bool kUniformDensity = false; /* (see WindowCellTallyT) */
+  __device__ __forceinline__ bool inside() const { return false; }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
     const int cellx = pcellx - a.x_off;
@@ -129,6 +131,8 @@ constexpr int kWindowCellsWithFlux = 88;
 template <bool kWithFlux>
 struct WindowTallyT {
   static constexpr bool kFlux = kWithFlux;
+  static constexpr bool kUniformDensity = false;
+  __device__ __forceinline__ bool inside() const { return false; }
   static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
   lds_double* window; /* LDS, W*W, row-major (flux: the next W*W) */
   int ox;         /* local cell coordinates of window element (0,0) */
@@ -164,12 +168,20 @@ struct WindowTallyT {
 /* The same destination for a cell whose window coordinates the caller has already
  * worked out (the stream kernel needs them anyway, to decide whether a particle
  * that left the window should wait for the next pass). */
-template <bool kWithFlux>
+template <bool kWithFlux, bool kUniform = false>
 struct WindowCellTallyT {
   static constexpr bool kFlux = kWithFlux;
+  /* kUniform: the density of every cell of the window, and of the cells around it, is the
+   * same bits (TiledArgs::tile_uniform: checked on the device every step).  A history that
+   * leaves a cell INSIDE such a window enters a cell of the density it already has: its
+   * crossing needs neither the load of the new cell's density nor the compare that
+   * follows it -- the one load of the facet loop whose result the next trip waits for.
+   * The stream kernel compiles its facet loop for both kinds of window. */
+  static constexpr bool kUniformDensity = kUniform;
   static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */
+  __device__ __forceinline__ bool inside() const { return (lx < (unsigned)W) & (ly < (unsigned)W); }
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
     if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
@@ -893,7 +905,12 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     dens_x = (dens_x < 0) ? 0 : ((dens_x >= a.nx) ? a.nx - 1 : dens_x);
     dens_y = (dens_y < 0) ? 0 : ((dens_y >= a.ny) ? a.ny - 1 : dens_y);
   }
-  const double new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
+  /* (a facet loop compiled for windows of one density, Tally::kUniformDensity, has no load
+   * here: only a history that leaves a cell outside the window loads, below) */
+  double new_density = h.local_density;
+  if (!Tally::kUniformDensity) {
+    new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
+  }
 #endif
 
   const double distance_to_facet = h.distance;
@@ -979,6 +996,14 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
    * sinks both divides below the branch that consumes the load */
   asm volatile("" : "+v"(h.mfp_to_collision), "+v"(h.dt_to_census));
 
+#if !defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
+  if (Tally::kUniformDensity) {
+    if (tally.inside()) {
+      return; /* the cell entered has the density this history carries */
+    }
+    new_density = *mesh_element(a.density, dens_y * a.nx + dens_x); /* (rare, dependent) */
+  }
+#endif
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
     macroscopic_from_density<kChecked>(h);

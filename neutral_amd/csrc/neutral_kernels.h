@@ -204,6 +204,8 @@ struct TiledArgs {
   int fine_index_n;
   long long fine_index_base;
   int fine_index_shift;
+  unsigned char* tile_uniform; /* ntiles: 1 when every cell of the tile's window and of the ring
+                                  around it holds one density (recomputed every step) */
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants,
                               passes used */
   int chunk_particles;     /* particles one workgroup takes at a time */

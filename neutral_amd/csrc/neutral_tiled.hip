@@ -47,6 +47,7 @@
  */
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "neutral_kernels.h"
 
@@ -588,6 +589,45 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   }
 }
 
+/* One workgroup per tile: does every cell of the tile's tally window (the W x W cells the
+ * stream kernel centres on it) AND of the ring of cells around it hold the same density,
+ * bit for bit?  Then a history that leaves a cell inside the window enters a cell of the
+ * density it has, and its crossing skips the load and the compare (neutral_history.h:
+ * WindowCellTallyT::uniform).  Asked every step: the mesh is the caller's. */
+__global__ __launch_bounds__(kSortBlock) void tile_uniform_kernel(SolveArgs a, TiledArgs t, int window_cells) {
+  __shared__ int s_differs;
+  if (threadIdx.x == 0) {
+    s_differs = 0;
+  }
+  __syncthreads();
+  const int tile = (int)blockIdx.x;
+  const int margin = (window_cells - (1 << t.tile_shift)) >> 1;
+  int x0 = ((tile % t.tiles_x) << t.tile_shift) - margin - 1;
+  int y0 = ((tile / t.tiles_x) << t.tile_shift) - margin - 1;
+  int x1 = x0 + window_cells + 2; /* (exclusive) */
+  int y1 = y0 + window_cells + 2;
+  x0 = (x0 < 0) ? 0 : x0;
+  y0 = (y0 < 0) ? 0 : y0;
+  x1 = (x1 > a.nx) ? a.nx : x1;
+  y1 = (y1 > a.ny) ? a.ny : y1;
+  const int w = x1 - x0;
+  const int n = w * (y1 - y0);
+  const long long first = __double_as_longlong(a.density[(size_t)y0 * a.nx + x0]);
+  bool differs = false;
+  for (int i = threadIdx.x; i < n; i += kSortBlock) {
+    const int y = y0 + i / w;
+    const int x = x0 + i % w;
+    differs |= (__double_as_longlong(a.density[(size_t)y * a.nx + x]) != first);
+  }
+  if (__ballot(differs) != 0 && (threadIdx.x & 63) == 0) {
+    s_differs = 1; /* (benign race: every writer writes 1) */
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    t.tile_uniform[tile] = s_differs ? 0 : 1;
+  }
+}
+
 /* ---- 2. streaming kernel with the LDS tally window ------------------------------ */
 
 template <int kW>
@@ -703,6 +743,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       win_oy = ((cur_tile / t.tiles_x) << t.tile_shift) - margin;
       __syncthreads();
     }
+    /* does every cell of the window, and around it, hold one density?  (wave-uniform) */
+    const bool uniform_window =
+        windowed && t.tile_uniform &&
+        __builtin_amdgcn_readfirstlane((int)t.tile_uniform[cur_tile]) != 0;
     /* an un-windowed chunk sees a window that contains no cell */
     tally.ox = __builtin_amdgcn_readfirstlane(windowed ? win_ox : (1 << 30));
     tally.oy = __builtin_amdgcn_readfirstlane(windowed ? win_oy : (1 << 30));
@@ -783,14 +827,19 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
          * end of the history */
         if (h.ev == kEvFacet) {
           int crossed = kStreamRepeat; /* facets this lane crosses in this pass */
+          /* the facet loop, compiled twice: for a window whose cells -- and the ring of cells
+           * around it -- all hold one density (no density load, no compare while the history
+           * is inside it: WindowCellTallyT<, true>), and for any other */
+          auto run_facets = [&](auto uniform_density) {
+          constexpr bool kUniform = decltype(uniform_density)::value;
 #pragma unroll 1
           for (int rep = 0; rep < kStreamRepeat; ++rep) {
             /* outside the window with a long way to go: continue in the pass that
              * centres a window on wherever the particle is by then */
             bool leave = false;
-            const WindowCellTallyT<kFlux> cell_tally{tally.window,
-                                                     (unsigned)(h.cellx - a.x_off - tally.ox),
-                                                     (unsigned)(h.celly - a.y_off - tally.oy)};
+            const WindowCellTallyT<kFlux, kUniform> cell_tally{
+                tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
+                (unsigned)(h.celly - a.y_off - tally.oy)};
             const bool in_window = (cell_tally.lx < (unsigned)kW) & (cell_tally.ly < (unsigned)kW);
             if (windowed && t.allow_migrate && !in_window) {
               const double ahead = h.speed * h.dt_to_census;
@@ -828,6 +877,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             if (!goes_on) {
               break;
             }
+          }
+          };
+          if (uniform_window) {
+            run_facets(std::true_type{});
+          } else {
+            run_facets(std::false_type{});
           }
           if (kCarryTargets) {
             /* the event that ended the run of crossings (or another facet), from the
@@ -1331,6 +1386,14 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
 
+  static const bool no_uniform = getenv("NEUTRAL_NO_UNIFORM_WINDOWS") != nullptr; /* (A/B knob) */
+  if (no_uniform) {
+    t.tile_uniform = nullptr;
+  }
+  if (first_pass == 0 && t.tile_uniform && a.pad == 0) {
+    hipLaunchKernelGGL(tile_uniform_kernel, dim3(t.ntiles), dim3(kSortBlock), 0, stream, a, t,
+                       a.flux_tally ? kWindowCellsWithFlux : kWindow);
+  }
   /* plan.stream_passes passes, back to back: nothing here waits for the device (the
    * caller reads the migrant counter with the step's counters and comes back for
    * more if the step outran the plan) */

@@ -24,10 +24,15 @@ BUILD = os.path.join(ROOT, "neutral_amd", "build")
 TARGETS = {
     "collide": ("neutral_kernels-hip-amdgcn-amd-amdhsa-gfx950.s",
                 "_ZN7neutral22history_regroup_kernelILb1ELb1ELb0ELb0EEEvNS_9SolveArgsE",
-                r"v_alignbit_b32", 60),
+                r"v_alignbit_b32", 60, None, 0),
+    # the facet loop is compiled twice (neutral_tiled.hip: run_facets): for windows of one
+    # density (no density load in the trip) and for any other
     "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
               "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-              r"v_mul_f64", 12),
+              r"v_mul_f64", 12, r"v_cmp_ne_u64", 1),
+    "facet_uniform": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
+                      "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
+                      r"v_mul_f64", 12, r"v_cmp_ne_u64", 0),
 }
 
 # Issue cycles one wave64 instruction holds its SIMD for, by opcode, measured with
@@ -102,10 +107,16 @@ def loops(items):
     return out
 
 
-def hot_loop(items, marker, min_marker):
+def hot_loop(items, marker, min_marker, also=None, also_min=0):
+    """the smallest loop with min_marker `marker` opcodes; `also`: it must (also_min = 1) or
+    must not (0) hold that opcode too -- the density compare tells the two facet loops apart"""
     best = None
     for a, b in loops(items):
         n = sum(1 for _, op, _ in items[a:b + 1] if op and re.match(marker, op))
+        if also is not None:
+            m = sum(1 for _, op, _ in items[a:b + 1] if op and re.match(also, op))
+            if (m >= 1) != (also_min >= 1):
+                continue
         if n >= min_marker and (best is None or (b - a) < (best[1] - best[0])):
             best = (a, b)
     if best is None:
@@ -132,9 +143,9 @@ def main():
                   f"mean {m['mean_cycles_per_valu']:.3f} ({m['mean_cycles_per_valu_low']:.3f}-"
                   f"{m['mean_cycles_per_valu_high']:.3f})")
         return
-    fname, symbol, marker, min_marker = TARGETS[args.target]
+    fname, symbol, marker, min_marker, also, also_min = TARGETS[args.target]
     items = parse(function_body(os.path.join(BUILD, fname), symbol))
-    a, b = hot_loop(items, marker, min_marker)
+    a, b = hot_loop(items, marker, min_marker, also, also_min)
     span = items[a:b + 1]
     if args.dump:
         for lab, op, text in span:
