@@ -162,6 +162,8 @@ struct State {
   double mesh_width = 1.0;
   double mesh_height = 1.0;
   const void* extent_edges = nullptr;
+  double edge_dx = 0.0; /* the caller's edgedx[pad] / edgedy[pad] for the same mesh (0: none) */
+  double edge_dy = 0.0;
   int extent_nx = 0;
   int extent_ny = 0;
   int tiled_particles = 0;
@@ -355,6 +357,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   if (!t.ctrl) {
     HIP_CHECK(hipMalloc((void**)&t.ctrl, sizeof(unsigned) * 16));
     HIP_CHECK(hipMemsetAsync(t.ctrl, 0, sizeof(unsigned) * 16, g.stream));
+    HIP_CHECK(hipMalloc((void**)&t.edges_computed, sizeof(int)));
+    HIP_CHECK(hipMemsetAsync(t.edges_computed, 0, sizeof(int), g.stream));
   }
   t.tile_shift = shift;
   t.window_min_particles = neutral::tiled_window_min_particles(shift);
@@ -785,8 +789,6 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                         uint64_t* reduce_array1, uint64_t* reduce_array2,
                         uint64_t* facet_events, uint64_t* collision_events) {
   (void)neighbours;
-  (void)edgedx;
-  (void)edgedy;
   (void)reduce_array0;
   (void)reduce_array1;
   (void)reduce_array2;
@@ -852,6 +854,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.density = density;
   a.edgex = edgex;
   a.edgey = edgey;
+  a.edge_dx = 0.0;
+  a.edge_dy = 0.0;
   a.tally = energy_deposition_tally;
   a.flux_tally = g.flux_tally;
   a.susp_track = nullptr;
@@ -914,7 +918,15 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       HIP_CHECK(hipMemcpyAsync(&e[2], edgey + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
       HIP_CHECK(hipMemcpyAsync(&e[3], edgey + pad + ny, sizeof(double), hipMemcpyDeviceToHost,
                                g.stream));
+      /* (and the spacings the host layer made the edges from, if the caller passes them) */
+      double d[2] = {0.0, 0.0};
+      if (edgedx && edgedy) {
+        HIP_CHECK(hipMemcpyAsync(&d[0], edgedx + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+        HIP_CHECK(hipMemcpyAsync(&d[1], edgedy + pad, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+      }
       wait_for_stream();
+      g.edge_dx = d[0];
+      g.edge_dy = d[1];
       g.mesh_width = (e[1] > e[0]) ? e[1] - e[0] : 1.0;
       g.mesh_height = (e[3] > e[2]) ? e[3] - e[2] : 1.0;
       g.extent_edges = (const void*)edgex;
@@ -931,6 +943,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     /* (after a possible import / pending write-back above: are the arrays current now?) */
     a.export_skip_long_dead = (pass_export && !decomposed && g.soa_valid) ? 1 : 0;
     if (getenv("NEUTRAL_HIP_EXPORT_ALL")) a.export_skip_long_dead = 0; /* experiment knob */
+    a.edge_dx = g.edge_dx;
+    a.edge_dy = g.edge_dy;
     g.tiled.cells_per_x = (double)nx / g.mesh_width;
     g.tiled.cells_per_y = (double)ny / g.mesh_height;
   } else {

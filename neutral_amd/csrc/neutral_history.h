@@ -710,11 +710,36 @@ __device__ __forceinline__ void aim_targets(History& h, const SolveArgs& a) {
   h.wall_y = (h.omega_y > 0.0) ? a.global_ny - 1 : ((h.omega_y < 0.0) ? 0 : -1);
 }
 
+/* Edge `index` of an axis (an index into the edge array as the kernel sees it): loaded, or
+ * -- kComputed: the device has checked this step that the formula reproduces the array --
+ * worked out: one conversion and one multiplication, rounded as the host's were (never
+ * contracted into the addition that follows), and no load for the trip to wait for. */
+/* (the product is the host's product, rounded by itself: contraction is switched off for
+ * it, or the compiler fuses it with the addition of the open-bound correction that follows
+ * and the last bit of a target -- hence of every position -- changes.  __dmul_rn does not
+ * prevent that here: it is a plain `*`.) */
+__device__ __forceinline__ double edge_from_formula(double spacing, int number) {
+#pragma clang fp contract(off)
+  const double product = spacing * (double)number;
+  return product;
+}
+template <bool kComputed>
+__device__ __forceinline__ double edge_x(const SolveArgs& a, int index) {
+  return kComputed ? edge_from_formula(a.edge_dx, index + a.x_off - a.pad)
+                   : *mesh_element(a.edgex, index);
+}
+template <bool kComputed>
+__device__ __forceinline__ double edge_y(const SolveArgs& a, int index) {
+  return kComputed ? edge_from_formula(a.edge_dy, index + a.y_off - a.pad)
+                   : *mesh_element(a.edgey, index);
+}
+
 /* the targets of the history's cell and direction, from the edge arrays */
+template <bool kComputedEdges = false>
 __device__ __forceinline__ void load_targets(History& h, const SolveArgs& a) {
   aim_targets(h, a);
-  h.target_x = *mesh_element(a.edgex, h.target_ix) + h.target_adj_x;
-  h.target_y = *mesh_element(a.edgey, h.target_iy) + h.target_adj_y;
+  h.target_x = __dadd_rn(edge_x<kComputedEdges>(a, h.target_ix), h.target_adj_x);
+  h.target_y = __dadd_rn(edge_y<kComputedEdges>(a, h.target_iy), h.target_adj_y);
 }
 
 template <bool kWatchdog = true>
@@ -838,7 +863,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
  * cell it enters are loaded here, next to the density, and the reflection -- rare -- sits
  * behind one wave-uniform branch instead of eight selects per facet. */
 template <bool kChecked, bool kCachedReciprocals = false, int kDomain = 2, bool kCarryTargets = false,
-          typename Tally>
+          bool kComputedEdges = false, typename Tally>
 __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, const Tally& tally) {
   /* step to the neighbour cell, or reflect at the outer boundary (:333-369), as
    * selects: the branch ladder of the reference costs ~35 scalar instructions of
@@ -886,8 +911,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     edge_ahead_x = (double)ex * (1.0 / (double)a.nx);
     edge_ahead_y = (double)ey * (1.0 / (double)a.ny);
 #else
-    edge_ahead_x = *mesh_element(a.edgex, ex);
-    edge_ahead_y = *mesh_element(a.edgey, ey);
+    edge_ahead_x = edge_x<kComputedEdges>(a, ex);
+    edge_ahead_y = edge_y<kComputedEdges>(a, ey);
 #endif
   }
 #if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
@@ -964,8 +989,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
       if (reflect) {
         /* turned round in the same cell: the other edge of it (a dependent load, here only) */
         aim_targets(h, a);
-        double ex = *mesh_element(a.edgex, h.target_ix);
-        double ey = *mesh_element(a.edgey, h.target_iy);
+        double ex = edge_x<kComputedEdges>(a, h.target_ix);
+        double ey = edge_y<kComputedEdges>(a, h.target_iy);
         /* (waited for here, inside the rare branch: the common path then knows how many
          * loads are in flight where the paths join, and waits for the edges alone) */
         asm volatile("" : "+v"(ex), "+v"(ey));
@@ -982,8 +1007,8 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   h.cellx = ncellx;
   h.celly = ncelly;
   if (kCarryTargets) {
-    h.target_x = edge_ahead_x + h.target_adj_x;
-    h.target_y = edge_ahead_y + h.target_adj_y;
+    h.target_x = __dadd_rn(edge_ahead_x, h.target_adj_x);
+    h.target_y = __dadd_rn(edge_ahead_y, h.target_adj_y);
     /* the next loop head's distance to the facet needs the edges, not the density: it is
      * worked out here, ahead of the wait for the density below (the loads were issued in
      * that order), and pinned there */

@@ -106,6 +106,14 @@ struct SolveArgs {
   const double* density;
   const double* edgex;
   const double* edgey;
+  /* The mesh as a formula, when it is one: edge[pad + i] == edge_d * (double)(off + i), bit
+   * for bit, for every edge of both axes (the way the reference's host layer makes uniform
+   * meshes: edgedx[i] * (x_off + i - pad)).  The spacings are read once per mesh from the
+   * caller's edgedx / edgedy (0: none given); whether the formula HOLDS is checked on the
+   * device every step (TiledArgs::edges_computed), and the stream kernel then works the two
+   * edges of a crossing out instead of loading them. */
+  double edge_dx;
+  double edge_dy;
   const double* scatter_keys;
   const double* scatter_values;
   int scatter_n;
@@ -204,6 +212,7 @@ struct TiledArgs {
   int fine_index_n;
   long long fine_index_base;
   int fine_index_shift;
+  int* edges_computed;     /* [device] 1: SolveArgs::edge_dx / edge_dy reproduce both edge arrays */
   unsigned char* tile_uniform; /* ntiles: 1 when every cell of the tile's window and of the ring
                                   around it holds one density (recomputed every step) */
   unsigned* ctrl;          /* 8 words: chunk head, #chunks, queue length, #active, #migrants,

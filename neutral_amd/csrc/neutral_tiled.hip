@@ -628,6 +628,33 @@ __global__ __launch_bounds__(kSortBlock) void tile_uniform_kernel(SolveArgs a, T
   }
 }
 
+/* Single workgroup: is every edge of both axes the host layer's formula, edge[pad + i] ==
+ * edge_d * (double)(off + i), bit for bit?  (SolveArgs::edge_dx ...)  Asked every step: the
+ * arrays are the caller's. */
+__global__ __launch_bounds__(1024) void edges_check_kernel(SolveArgs a, TiledArgs t) {
+  __shared__ int s_differs;
+  if (threadIdx.x == 0) {
+    s_differs = 0;
+  }
+  __syncthreads();
+  bool differs = !(a.edge_dx > 0.0) || !(a.edge_dy > 0.0);
+  for (int i = threadIdx.x; i <= a.nx; i += 1024) {
+    differs |= __double_as_longlong(edge_from_formula(a.edge_dx, i + a.x_off)) !=
+               __double_as_longlong(a.edgex[i + a.pad]);
+  }
+  for (int i = threadIdx.x; i <= a.ny; i += 1024) {
+    differs |= __double_as_longlong(edge_from_formula(a.edge_dy, i + a.y_off)) !=
+               __double_as_longlong(a.edgey[i + a.pad]);
+  }
+  if (__ballot(differs) != 0 && (threadIdx.x & 63) == 0) {
+    s_differs = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *t.edges_computed = s_differs ? 0 : 1;
+  }
+}
+
 /* ---- 2. streaming kernel with the LDS tally window ------------------------------ */
 
 template <int kW>
@@ -686,6 +713,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   }
 
   const int nchunks = (int)t.ctrl[kCtrlNumChunks];
+  /* do SolveArgs::edge_dx / edge_dy reproduce the edge arrays this step?  (wave-uniform) */
+  const bool edges_computed =
+      kCarryTargets && t.edges_computed && __builtin_amdgcn_readfirstlane(*t.edges_computed) != 0;
   /* histories without a window move on after a window's worth of facets when the
    * pass has windows to offer (wave-uniform) */
   const bool budget_on = t.allow_migrate && t.ctrl[kCtrlWindowed] != 0;
@@ -809,7 +839,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             refresh_speed_reciprocal<kChecked>(h); /* no collision here: the speed stays */
             refresh_mfp_reciprocal<kChecked>(h);
             if (kCarryTargets) {
-              load_targets(h, a);
+              /* (wave-uniform branch: computed or loaded, the same bits) */
+              if (edges_computed) {
+                load_targets<true>(h, a);
+              } else {
+                load_targets<false>(h, a);
+              }
               decide_carried(h);
               h.nevents++; /* (as decide() counts it) */
             } else {
@@ -830,8 +865,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           /* the facet loop, compiled twice: for a window whose cells -- and the ring of cells
            * around it -- all hold one density (no density load, no compare while the history
            * is inside it: WindowCellTallyT<, true>), and for any other */
-          auto run_facets = [&](auto uniform_density) {
+          auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
+          constexpr bool kEdges = decltype(computed_edges)::value;
 #pragma unroll 1
           for (int rep = 0; rep < kStreamRepeat; ++rep) {
             /* outside the window with a long way to go: continue in the pass that
@@ -853,7 +889,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               break;
             }
             /* (tallies the cell it leaves: this one) */
-            cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets>(h, a, cell_tally);
+            cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
             if (kDomain) {
               /* the neighbour cell may belong to another rank: the history stops on the
                * facet, before anything of that cell (edges, density) is looked at */
@@ -879,10 +915,20 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
           }
           };
+          /* ... and for a mesh whose edges the device has found to follow the host layer's
+           * formula this step (computed, not loaded) and for any other: four copies, one runs */
           if (uniform_window) {
-            run_facets(std::true_type{});
+            if (edges_computed) {
+              run_facets(std::true_type{}, std::true_type{});
+            } else {
+              run_facets(std::true_type{}, std::false_type{});
+            }
           } else {
-            run_facets(std::false_type{});
+            if (edges_computed) {
+              run_facets(std::false_type{}, std::true_type{});
+            } else {
+              run_facets(std::false_type{}, std::false_type{});
+            }
           }
           if (kCarryTargets) {
             /* the event that ended the run of crossings (or another facet), from the
@@ -1389,6 +1435,14 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   static const bool no_uniform = getenv("NEUTRAL_NO_UNIFORM_WINDOWS") != nullptr; /* (A/B knob) */
   if (no_uniform) {
     t.tile_uniform = nullptr;
+  }
+  static const bool no_formula = getenv("NEUTRAL_NO_COMPUTED_EDGES") != nullptr; /* (A/B knob) */
+  if (first_pass == 0 && t.edges_computed) {
+    if (no_formula) {
+      (void)hipMemsetAsync(t.edges_computed, 0, sizeof(int), stream);
+    } else {
+      hipLaunchKernelGGL(edges_check_kernel, dim3(1), dim3(1024), 0, stream, a, t);
+    }
   }
   if (first_pass == 0 && t.tile_uniform && a.pad == 0) {
     hipLaunchKernelGGL(tile_uniform_kernel, dim3(t.ntiles), dim3(kSortBlock), 0, stream, a, t,

@@ -320,6 +320,35 @@ def test_history_matches_oracle(iface, make_problem, cs, deck, nx, n, its, dt, v
     sim.close()
 
 
+@pytest.mark.parametrize("variant", [0, 2])
+def test_uneven_mesh_matches_oracle(iface, make_problem, cs, variant):
+    """Edges that are NOT the host layer's formula edge[i] = dx * i (cells of growing width):
+    the device-side check of the mesh formula fails, the stream kernel loads its edges, and
+    the histories are the oracle's -- as on the uniform meshes, where it works them out."""
+    prob = make_problem("csp", nx=96, nparticles=20000, iterations=3, dt=1.0e-6)
+    t = np.linspace(0.0, 1.0, prob.nx + 1)
+    prob.edgex[:] = prob.edgex[-1] * (0.7 * t + 0.3 * t * t)   # monotone, uneven
+    prob.edgey[:] = prob.edgey[-1] * (0.8 * t + 0.2 * t ** 3)
+    prob.edgedx[:-1] = np.diff(prob.edgex)
+    prob.edgedy[:-1] = np.diff(prob.edgey)
+    sim = iface.Simulation(prob, *cs, variant=variant)
+    ref = ob.OracleRun(prob, *cs)
+    sim.inject()
+    ref.inject()
+    for tt in (1, 2, 3):
+        g, c = sim.step(tt), ref.step(tt)
+        assert (g.nprocessed, g.facets, g.collisions) == (c.nprocessed, c.facets, c.collisions)
+    gp, cp = sim.particle_arrays(), ref.particles.as_dict()
+    for f in ("cellx", "celly", "dead"):
+        assert np.array_equal(gp[f], cp[f]), f
+    for f in ("energy", "weight", "dt_to_census", "x", "y"):
+        assert _rel(gp[f], cp[f]) < STATE_TOL, f
+    tg, tc = sim.tally_host(), ref.tally
+    assert np.linalg.norm(tg - tc) / np.linalg.norm(tc) < TALLY_L2_TOL
+    assert np.array_equal(tg == 0.0, tc == 0.0)
+    sim.close()
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_distinct_tables_take_the_two_search_path(iface, make_problem, cs, variant):
     keys, values = cs
