@@ -42,6 +42,7 @@ matrix)
   NEUTRAL_EAGER_EXPORT=1 python tools/ablate.py matrix --run "stream 4000 1000000 1 2" \
     --run "csp 4000 1000000 10 2" >> $out/default_decks.log 2>&1
   bash tools/share_bench.sh $tag/share > $out/share_bench.log 2>&1
+  bash tools/ktrace.sh share8 csp 400 12500000 10 2 > $out/ktrace_share8.txt 2>&1
   tail -4 $out/baseline_configs.log; cat $out/default_decks.log | cut -c1-160; tail -5 $out/share_bench.log
   ;;
 esac
