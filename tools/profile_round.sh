@@ -31,7 +31,7 @@ priced)
   # every workload's bench line again, priced with the coefficients committed by the parts above
   for w in "stream 10 1" "scatter 2 0" "split 1 0" "stream4000 4 1" "csp4000 10 1"; do
     set -- $w
-    python3 bench.py --workload $1 --steps $2 --warmup $3 --no-cpu-baseline > $out/$1/bench_priced.json 2> $out/$1/bench_priced.err
+    mkdir -p $out/$1; python3 bench.py --workload $1 --steps $2 --warmup $3 --no-cpu-baseline > $out/$1/bench_priced.json 2> $out/$1/bench_priced.err
     tail -c 200 $out/$1/bench_priced.json; echo
   done
   ;;
