@@ -181,8 +181,8 @@ void ensure_scratch() {
   }
   /* scratch of another device (if any) is abandoned: a process drives one GPU */
   HIP_CHECK(hipMalloc((void**)&g.d_counters, 2 * sizeof(neutral::StepCounters)));
-  HIP_CHECK(hipMalloc((void**)&g.d_check, 8 * sizeof(unsigned long long)));
-  HIP_CHECK(hipMemset(g.d_check, 0, 8 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMalloc((void**)&g.d_check, 16 * sizeof(unsigned long long)));
+  HIP_CHECK(hipMemset(g.d_check, 0, 16 * sizeof(unsigned long long))); /* ([8..12]: accumulators) */
   HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
   HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));
   HIP_CHECK(hipMalloc((void**)&g.d_words, sizeof(unsigned long long) * 16));

@@ -271,10 +271,11 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream);
 /* out[0] |= 1 when a value lies outside [2^-100, 2^100] (zero, negative, inf, NaN too) */
 hipError_t launch_unphysical_values(const double* v, long long n, unsigned long long* out,
                                     hipStream_t stream);
-/* out: 8 words -- [0] the abort flag of the step's history kernels = [6] | [7]; [1..3]
+/* out: 16 words, the first 8 -- [0] the abort flag of the step's history kernels = [6] | [7]; [1..3]
  * hashes and identity; [4] a key or value lies outside [2^-100, 2^100]; [5] (written by
  * launch_unphysical_values before this kernel) a density does; [6] the expected hashes /
- * identity do not match; [7] fast_arithmetic was launched and [4] or [5] is set */
+ * identity do not match; [7] fast_arithmetic was launched and [4] or [5] is set; [8..12]
+ * the kernel's own accumulators (zero between launches) */
 hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const double* ka,
                                const double* va, int na, unsigned long long expect_hash_s,
                                unsigned long long expect_hash_a, int expect_same,

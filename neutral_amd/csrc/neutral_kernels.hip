@@ -776,38 +776,43 @@ hipError_t launch_unphysical_values(const double* v, long long n, unsigned long 
   return hipGetLastError();
 }
 
+/* (A grid of kTablesBlocks workgroups: one workgroup took 77 us for the shipped tables, on
+ * the critical path of every step -- 1 % of an 8-GPU share.  Every workgroup folds its part
+ * into five accumulator words with atomics and takes a ticket; the one that draws the last
+ * ticket reads the totals back, writes the verdicts and clears the accumulators for the next
+ * launch.) */
+constexpr int kTablesBlocks = 30;
+
 __global__ __launch_bounds__(1024) void tables_check_kernel(
     const double* ks, const double* vs, int ns, const double* ka, const double* va, int na,
     unsigned long long expect_hash_s, unsigned long long expect_hash_a, int expect_same,
-    int fast_arithmetic, unsigned long long* out) {
+    int fast_arithmetic, unsigned long long* out, unsigned long long* acc) {
   __shared__ unsigned long long s_hs[16], s_ha[16];
   __shared__ int s_diff[16];
   __shared__ int s_odd[16];
   unsigned long long hs = 0, ha = 0;
   int diff = (ns != na) ? 1 : 0;
   bool odd = false; /* a key or a value the unwrapped arithmetic is not exact on */
-  for (int i = threadIdx.x; i < ns; i += 1024) {
+  const int first = (int)blockIdx.x * 1024 + (int)threadIdx.x;
+  const int stride = (int)gridDim.x * 1024;
+  for (int i = first; i < ns; i += stride) {
     odd = odd || !is_physical(ks[i]) || !is_physical(vs[i]);
-  }
-  for (int i = threadIdx.x; i < na; i += 1024) {
-    odd = odd || !is_physical(ka[i]) || !is_physical(va[i]);
-  }
-  const int wave_odd = (__ballot(odd) != 0) ? 1 : 0;
-  for (int i = threadIdx.x; i < ns; i += 1024) {
     const unsigned long long k = (unsigned long long)__double_as_longlong(ks[i]);
     hs += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
   }
-  for (int i = threadIdx.x; i < na; i += 1024) {
+  for (int i = first; i < na; i += stride) {
+    odd = odd || !is_physical(ka[i]) || !is_physical(va[i]);
     const unsigned long long k = (unsigned long long)__double_as_longlong(ka[i]);
     ha += mix64(k ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1)));
   }
   if (ns == na) {
-    for (int i = threadIdx.x; i < ns; i += 1024) {
+    for (int i = first; i < ns; i += stride) {
       /* bit comparison: NaNs and signed zeros must not compare "equal enough" */
       diff |= (__double_as_longlong(ks[i]) != __double_as_longlong(ka[i])) ||
               (__double_as_longlong(vs[i]) != __double_as_longlong(va[i]));
     }
   }
+  const int wave_odd = (__ballot(odd) != 0) ? 1 : 0;
   for (int off = 32; off > 0; off >>= 1) {
     hs += __shfl_down(hs, off, 64);
     ha += __shfl_down(ha, off, 64);
@@ -830,6 +835,23 @@ __global__ __launch_bounds__(1024) void tables_check_kernel(
       diff |= s_diff[w];
       any_odd |= s_odd[w];
     }
+    atomicAdd(&acc[0], hs);
+    atomicAdd(&acc[1], ha);
+    if (diff) atomicOr(&acc[2], 1ull);
+    if (any_odd) atomicOr(&acc[3], 1ull);
+    __threadfence();
+    const unsigned long long ticket = atomicAdd(&acc[4], 1ull);
+    if (ticket != (unsigned long long)gridDim.x - 1ull) {
+      return;
+    }
+    /* the last workgroup: everybody's contribution is in (read back through the atomics'
+     * own path), and the accumulators start the next launch from zero */
+    __threadfence();
+    hs = atomicExch(&acc[0], 0ull);
+    ha = atomicExch(&acc[1], 0ull);
+    diff = (int)atomicExch(&acc[2], 0ull);
+    any_odd = (int)atomicExch(&acc[3], 0ull);
+    atomicExch(&acc[4], 0ull);
     const int same = diff ? 0 : 1;
     out[1] = hs;
     out[2] = ha;
@@ -853,8 +875,10 @@ hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const
                                unsigned long long expect_hash_a, int expect_same,
                                int fast_arithmetic, unsigned long long* out4,
                                hipStream_t stream) {
-  hipLaunchKernelGGL(tables_check_kernel, dim3(1), dim3(1024), 0, stream, ks, vs, ns, ka, va, na,
-                     expect_hash_s, expect_hash_a, expect_same, fast_arithmetic, out4);
+  /* (out4 + 8 ... out4 + 12: the accumulators, zero between launches) */
+  hipLaunchKernelGGL(tables_check_kernel, dim3(kTablesBlocks), dim3(1024), 0, stream, ks, vs, ns, ka,
+                     va, na, expect_hash_s, expect_hash_a, expect_same, fast_arithmetic, out4,
+                     out4 + 8);
   return hipGetLastError();
 }
 
