@@ -75,6 +75,13 @@ struct TableView {
   neutral::CsIndex fine = {nullptr, 0, 0, 0};
 };
 
+struct StepResults {
+  neutral::StepCounters counters[2];
+  unsigned long long check[8];
+  unsigned ctrl[16];
+  unsigned long long words[16];
+};
+
 struct State {
   hipStream_t stream = nullptr;
   uint64_t pid_base = 0;
@@ -102,6 +109,13 @@ struct State {
   hipEvent_t ev_streamed = nullptr; /* tiled variant: after the streaming kernel */
   hipEvent_t ev_collected = nullptr; /* tiled variant: after the collision queue is built */
   hipEvent_t ev_exported = nullptr; /* tiled variant: after the write-back to the SoA arrays */
+  /* What the host reads at the step's single wait -- the two counter records, the check
+   * words, the pipeline's control words, the step words -- lands in ONE block of pinned,
+   * device-mapped host memory, written by one small kernel at the end of the batch: four
+   * device-to-host copies into pageable memory cost 70-85 us each in the kernel trace
+   * (r03/kernel_stats.csv: __amd_rocclr_copyBuffer), a quarter of a millisecond per step. */
+  struct StepResults* h_results = nullptr; /* pinned host */
+  struct StepResults* d_results = nullptr; /* the same block as the device sees it */
   hipStream_t comm_stream = nullptr; /* several ranks: the exchange runs here, beside the write-back */
   hipEvent_t ev_exchanged = nullptr;
   TableView tables;
@@ -200,6 +214,11 @@ void ensure_scratch() {
   HIP_CHECK(hipEventCreate(&g.ev_exported));
   HIP_CHECK(hipEventCreateWithFlags(&g.ev_exchanged, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
+  if (!g.h_results) {
+    HIP_CHECK(hipHostMalloc((void**)&g.h_results, sizeof(StepResults), hipHostMallocMapped));
+    memset(g.h_results, 0, sizeof(StepResults));
+  }
+  HIP_CHECK(hipHostGetDevicePointer((void**)&g.d_results, g.h_results, 0));
   g.scratch_device = dev;
 }
 
@@ -508,6 +527,21 @@ enum StepWord : int {
   kStepWords = 16,
 };
 
+/* the step's results, into the pinned block the host reads after its wait (one workgroup) */
+__global__ void publish_results_kernel(const neutral::StepCounters* counters,
+                                       const unsigned long long* check, const unsigned* ctrl,
+                                       const unsigned long long* words, StepResults* out) {
+  const unsigned t = threadIdx.x;
+  const unsigned* c32 = (const unsigned*)counters;
+  unsigned* o32 = (unsigned*)out->counters;
+  for (unsigned i = t; i < 2 * sizeof(neutral::StepCounters) / 4; i += blockDim.x) {
+    o32[i] = c32[i];
+  }
+  if (t < 8) out->check[t] = check[t];
+  if (t < 16) out->ctrl[t] = ctrl ? ctrl[t] : 0u;
+  if (t < 16) out->words[t] = words ? words[t] : 0ull;
+}
+
 __global__ void pack_step_words_kernel(const neutral::StepCounters* c, const unsigned long long* check,
                                        const unsigned* ctrl, unsigned long long* w) {
   if (threadIdx.x != 0) {
@@ -569,6 +603,25 @@ void exchange_step(const neutral::SolveArgs& a, double* tally, bool tiled) {
 
 /* the caller's stream goes on only when the exchange is done (the step buffers are reused) */
 void finish_exchange() { HIP_CHECK(hipStreamWaitEvent(g.stream, g.ev_exchanged, 0)); }
+
+/* enqueues the publication of the batch's results; fetch_results() after the wait */
+void publish_results(bool tiled, bool with_words) {
+  hipLaunchKernelGGL(publish_results_kernel, dim3(1), dim3(64), 0, g.stream, g.d_counters, g.d_check,
+                     tiled ? (const unsigned*)g.tiled.ctrl : (const unsigned*)nullptr,
+                     with_words ? (const unsigned long long*)g.d_words
+                                : (const unsigned long long*)nullptr,
+                     g.d_results);
+  HIP_CHECK(hipGetLastError());
+}
+
+void fetch_results(neutral::StepCounters* hc, unsigned long long* check, unsigned* ctrl,
+                   unsigned long long* words) {
+  const StepResults& r = *g.h_results;
+  memcpy(hc, r.counters, sizeof(r.counters));
+  if (check) memcpy(check, r.check, sizeof(r.check));
+  if (ctrl) memcpy(ctrl, r.ctrl, sizeof(r.ctrl));
+  if (words) memcpy(words, r.words, sizeof(r.words));
+}
 
 /* Decomposed mesh, one round: this rank's emigrants (records of t.rec_out marked
  * kRecEmigrate) go to the ranks that own the cells they crossed into; what arrives
@@ -1095,17 +1148,14 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
 
     if (exchange) {
       finish_exchange();
-      HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
     }
-    /* the one wait of a steady-state step: counters, the pipeline's control words
-     * and the verdict on the table view */
+    /* the one wait of a steady-state step: counters, the pipeline's control words, the
+     * verdict on the table view and -- several ranks -- the step words, published by one
+     * small kernel into pinned host memory */
     unsigned long long check[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
-    HIP_CHECK(hipMemcpyAsync(check, g.d_check, sizeof(check), hipMemcpyDeviceToHost, g.stream));
-    if (tiled) {
-      HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, g.stream));
-    }
+    publish_results(tiled, exchange);
     wait_for_stream();
+    fetch_results(hc, check, tiled ? ctrl : nullptr, exchange ? words : nullptr);
     stage = StageMs(); /* (an attempt that was turned down did nothing worth timing) */
     harvest(true);
     /* the device's verdict: [6] the cached view of the tables is stale, [7] a fast attempt
@@ -1167,12 +1217,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {
           finish_exchange();
-          HIP_CHECK(hipMemcpyAsync(words, g.d_words, sizeof(words), hipMemcpyDeviceToHost, g.stream));
         }
-        HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
-        HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
-                                 g.stream));
+        publish_results(true, exchange);
         wait_for_stream();
+        fetch_results(hc, nullptr, ctrl, exchange ? words : nullptr);
         harvest(false);
         queue_total += exchange ? words[kWordQueued] : ctrl[2];
       }
@@ -1198,10 +1246,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                               g.ev_streamed, g.ev_collected, &passes));
         HIP_CHECK(hipEventRecord(g.ev_stop, g.stream));
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
-        HIP_CHECK(hipMemcpyAsync(hc, g.d_counters, sizeof(hc), hipMemcpyDeviceToHost, g.stream));
-        HIP_CHECK(hipMemcpyAsync(ctrl, g.tiled.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost,
-                                 g.stream));
+        publish_results(true, false);
         wait_for_stream();
+        fetch_results(hc, nullptr, ctrl, nullptr);
         harvest(false);
         queue_total += ctrl[2];
         finish_passes();

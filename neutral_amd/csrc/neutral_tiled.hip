@@ -500,8 +500,21 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
  * particles; a run of sparse tiles ends at the range's end. */
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   __shared__ unsigned s_chunks[1024];
+  /* the bucket offsets, staged once (coalesced) when they fit: every thread then sweeps
+   * its range of tiles twice, one dependent read per tile -- from global memory that was
+   * 33 us per launch on the shipped csp deck, 121 launches per ten steps */
+  constexpr int kStagedOffsets = 8192;
+  __shared__ unsigned s_offset[kStagedOffsets + 2];
   const int tid = threadIdx.x;
-  const unsigned nactive = t.tile_offset[t.nsort];
+  const bool staged = t.nsort + 1 <= kStagedOffsets;
+  if (staged) {
+    for (int i = tid; i <= t.nsort + 1; i += 1024) {
+      s_offset[i] = t.tile_offset[i];
+    }
+    __syncthreads();
+  }
+  const unsigned* offset = staged ? s_offset : t.tile_offset;
+  const unsigned nactive = offset[t.nsort];
   const int classes = t.reach_classes; /* (a tile's buckets follow each other) */
   long long per = (t.ntiles + 1023) / 1024;
   if (nactive > 0) {
@@ -544,8 +557,8 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
       }
     };
     for (int i = lo; i < hi; ++i) {
-      const unsigned begin = t.tile_offset[i * classes];
-      const unsigned end = t.tile_offset[(i + 1) * classes];
+      const unsigned begin = offset[i * classes];
+      const unsigned end = offset[(i + 1) * classes];
       if (end - begin >= (unsigned)t.window_min_particles) {
         emit(run_begin, run_end, 0u, 0u);
         run_begin = run_end = end;
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
     if (t.pass == 0) {
       t.ctrl[kCtrlPassesUsed] = 1;
       t.ctrl[kCtrlEmigrants] = 0;
-      t.ctrl[kCtrlFirstInactive] = t.tile_offset[t.nsort];
+      t.ctrl[kCtrlFirstInactive] = offset[t.nsort];
     } else if (nactive > 0) {
       t.ctrl[kCtrlPassesUsed] = (unsigned)t.pass + 1u;
     }
