@@ -52,6 +52,29 @@ def test_struct_layouts_match_the_reference_types():
         "cellx", "celly", "dead"]
 
 
+def test_step_stats_mirror_matches_the_c_struct(tmp_path):
+    """interface.StepStats (ctypes) against NeutralHipStepStats as a C compiler lays it out:
+    same size, same offset for every field (a field added to one and not the other would
+    silently shift everything behind it)."""
+    import neutral_amd.interface as iface
+    fields = [f[0] for f in iface.StepStats._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "neutral_hip.h"\n'
+        'int main(void) {\n  printf("%zu\\n", sizeof(NeutralHipStepStats));\n' +
+        "".join(f'  printf("{f} %zu\\n", offsetof(NeutralHipStepStats, {f}));\n' for f in fields) +
+        "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=gnu99", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe)])
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert int(lines[0]) == ctypes.sizeof(iface.StepStats)
+    for line in lines[1:]:
+        if line.strip():
+            name, off = line.split()
+            assert getattr(iface.StepStats, name).offset == int(off), name
+
+
 def test_deck_reader(tmp_path):
     p = tmp_path / "d.params"
     p.write_text("# comment line\n"
