@@ -104,6 +104,35 @@ def test_forked_ranks_reproduce_the_one_rank_run(tmp_path, cs, nranks, comm):
     assert f"{nranks} ranks, tally exchange over the host" in err
 
 
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
+@pytest.mark.skipif(_visible_gpus() < 2, reason="RCCL between GPUs needs two of them (the test box has one)")
+def test_two_gpus_exchange_over_rccl(tmp_path, cs):
+    """Two ranks on two DIFFERENT GPUs: the tally and the step words are all-reduced by RCCL
+    on the library's own stream (no host transport, no host collective); per-step event
+    counts equal the CPU oracle's, the global tally to 1e-10."""
+    from neutral_amd import cs_table, decks
+    run = tmp_path / "arch" / "neutral"
+    (run / "problems").mkdir(parents=True)
+    (tmp_path / "arch" / "arch.params").write_text("width 1.0\nheight 1.0\nsim_end 100.0\n")
+    cs_table.write_files(str(run))
+    rel = os.path.join("problems", "csp.params")
+    decks.write_deck("csp", str(run / rel))
+    sets = []
+    for kv in ("nx=128", "ny=128", "nparticles=200001", "iterations=4", "dt=1.0e-6"):
+        sets += ["--set", kv]
+    many, err = _run_driver(str(run), rel, sets + ["--gpus", "2"], {"NEUTRAL_COMM_TIMEOUT": "120"})
+    fn, cn, pn, tn = _numbers(many)
+    fo, co, po, to = _oracle_numbers(tmp_path, cs, **CSP_128)
+    assert (fo, co, po) == (fn, cn, pn), many[-1500:]
+    assert abs(tn - to) <= 1e-10 * abs(to)
+    assert "2 ranks, tally exchange over RCCL" in err
+
+
 @pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
 @pytest.mark.parametrize("nranks,grid", [(2, "2x1"), (4, "2x2")])
 def test_forked_ranks_with_a_decomposed_mesh(tmp_path, cs, nranks, grid):
