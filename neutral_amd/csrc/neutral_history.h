@@ -663,6 +663,35 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a, const Cel
   }
 }
 
+/* The collision stage's own loop head after a collision: is the next event another
+ * collision?  The comparisons of decide() (omp3/neutral.c:150) without the selects that
+ * name the event and its distance: a chain of collisions only asks this, and the history
+ * whose answer is no gets its event named by decide() then, once, from the same state.
+ * h.distance is the distance to the collision (what collide() moves by). */
+__device__ __forceinline__ bool next_is_collision(History& h, const CellEdges& e,
+                                                  double x_lo_open, double y_lo_open) {
+  /* (x_lo_open = e.x_lo - OPEN_BOUND_CORRECTION, worked out when the cell was entered: a
+   * collision changes the direction, not the cell) */
+  double distance_to_facet;
+#if !defined(NEUTRAL_NO_LO_OPEN)
+  calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv,
+                           (h.omega_x >= 0.0) ? e.x_hi : x_lo_open,
+                           (h.omega_y >= 0.0) ? e.y_hi : y_lo_open, distance_to_facet, h.x_facet);
+#else
+  /* (A/B: the two subtractions per collision instead of two values kept per cell;
+   * r03/experiments/collision_loop_head_ab.log) */
+  (void)x_lo_open;
+  (void)y_lo_open;
+  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
+                         e.x_lo, e.x_hi, e.y_lo, e.y_hi, distance_to_facet, h.x_facet);
+#endif
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  h.distance = distance_to_collision;
+  return (h.dt_to_census > 0.0) & (distance_to_collision < distance_to_facet) &
+         (distance_to_collision < distance_to_census);
+}
+
 /* loop head for a history that carries its targets (stream kernel): no edge loads here */
 __device__ __forceinline__ void decide_carried(History& h) {
   const bool running = (h.dt_to_census > 0.0);
@@ -755,10 +784,19 @@ __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
 #endif
 }
 
-/* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died. */
-template <bool kSameTables, bool kChecked, typename IndexPtr, typename Tally>
+/* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died.
+ *
+ * on_death(h) is called for a history that dies, AT the point of death (:243-252), with its
+ * final state: the caller stores it there.  Nothing returns early: the lanes of the dead go
+ * on through the rest of the body with everybody else (their instructions issue anyway, as
+ * long as one lane of the wave lives) and what they compute is never looked at again.
+ * With an early return every field the rest of the body updates was a conditional update,
+ * and the compiler kept old and new copies of it apart with register moves around the
+ * branch: 20 v_mov_b64 per pass of the collision stage, 4 % of its issue cycles. */
+template <bool kSameTables, bool kChecked, typename IndexPtr, typename Tally, typename OnDeath>
 __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
-                                        const CsLookup<IndexPtr>& ix, const Tally& tally) {
+                                        const CsLookup<IndexPtr>& ix, const Tally& tally,
+                                        const OnDeath& on_death) {
   const double distance_to_collision = h.distance;
   h.energy_deposition += deposit(h, distance_to_collision);
   if (Tally::kFlux) {
@@ -779,7 +817,8 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
    * bookkeeping and a branch than the few vector instructions it would skip. */
   const double absorbed_weight = h.weight * (1.0 - p_absorb);
   h.weight = absorbed ? absorbed_weight : h.weight;
-  if (__builtin_expect(absorbed & (h.energy < kMinEnergyOfInterest), 0)) {
+  const bool died = absorbed & (h.energy < kMinEnergyOfInterest);
+  if (__builtin_expect(died, 0)) {
     h.dead = 1;
     tally(a, h.cellx, h.celly, h.energy_deposition);
     h.energy_deposition = 0.0;
@@ -787,7 +826,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
       tally.flux(a, h.cellx, h.celly, h.track_length);
       h.track_length = 0.0;
     }
-    return true;
+    on_death(h);
   }
   /* The energy after the collision is known before the scattering angle is: the
    * table search for it (:281-286) starts here, and its first probe is in flight
@@ -844,7 +883,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   h.speed = speed_of<kChecked>(h.energy);
   refresh_direction(h);
   refresh_deposition_terms<kSameTables, kChecked>(h);
-  return false;
+  return died;
 }
 
 /* facet_event, omp3/neutral.c:303-380.

@@ -197,11 +197,15 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
     History h;
     load_particle(h, a, pid);
     prologue<kSameTables, kChecked>(h, a, ix);
+    bool died = false;
     for (;;) { /* omp3/neutral.c:134-197 */
       decide(h, a);
       if (h.ev == kEvCollision) {
         ncollisions++;
-        if (collide<kSameTables, kChecked>(h, a, ix, tally)) {
+        /* (a history that dies is stored where it dies: collide() has no early return) */
+        if (collide<kSameTables, kChecked>(h, a, ix, tally,
+                                           [&](const History& d) { store_particle(d, a, pid); })) {
+          died = true;
           break;
         }
       } else if (h.ev == kEvFacet) {
@@ -215,7 +219,9 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
         break;
       }
     }
-    store_particle(h, a, pid);
+    if (!died) {
+      store_particle(h, a, pid);
+    }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
 }
@@ -440,10 +446,13 @@ void history_regroup_kernel(SolveArgs a) {
   /* Queue mode (colliders only, VGPRs to spare at 3 waves/SIMD): the edges of the
    * history's cell stay in registers from one collision to the next. */
   CellEdges edges{0.0, 0.0, 0.0, 0.0};
+  double x_lo_open = 0.0, y_lo_open = 0.0; /* the lower edges less OPEN_BOUND_CORRECTION */
   auto next_event = [&](bool cell_changed) {
     if (kQueue) {
       if (cell_changed) {
         edges = load_edges(a, h.cellx, h.celly);
+        x_lo_open = edges.x_lo - kOpenBoundCorrection;
+        y_lo_open = edges.y_lo - kOpenBoundCorrection;
       }
       decide(h, a, edges);
     } else {
@@ -614,9 +623,18 @@ void history_regroup_kernel(SolveArgs a) {
           if (!kQueue) {
             ncollisions++;
           }
-          if (collide<kSameTables, kChecked>(h, a, ix, tally)) {
-            put_back<kQueue>(h, NEUTRAL_COLD_ARGS(a), pid);
+          if (collide<kSameTables, kChecked>(h, a, ix, tally, [&](const History& d) {
+                put_back<kQueue>(d, NEUTRAL_COLD_ARGS(a), pid);
+              })) {
             want = kWantRefill;
+          } else if (kQueue) {
+            /* (the chain goes on, or -- rarely -- its end gets a name) */
+            if (next_is_collision(h, edges, x_lo_open, y_lo_open)) {
+              h.ev = kEvCollision;
+            } else {
+              next_event_after_collision();
+              want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
+            }
           } else {
             next_event_after_collision();
             want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
