@@ -91,7 +91,12 @@ __device__ __forceinline__ void threefry2x64_20(uint64_t c0, uint64_t k0,
 __device__ __forceinline__ double u64_to_unit(uint64_t r) {
   constexpr double factor = 5.421010862427522170037264004349708557128906250e-20;      /* 2^-64 */
   constexpr double half_factor = 2.710505431213761085018632002174854278564453125e-20; /* 2^-65 */
-  return (double)r * factor + half_factor;
+  /* (double)r, round to nearest, as one fused operation on the two halves: hi * 2^32 is
+   * exact and the sum is rounded once -- the conversion the compiler expands to two
+   * conversions, a v_ldexp_f64 and an addition, is the same value in one instruction less */
+  const double as_double =
+      __builtin_fma((double)(uint32_t)(r >> 32), 4294967296.0, (double)(uint32_t)r);
+  return as_double * factor + half_factor;
 }
 
 /* omp3/neutral.c:632-652 */
@@ -161,12 +166,21 @@ struct CsIndex {
   long long base;
 };
 
+/* bucket of an energy: (bits >> shift) - base, clamped to [0, nbuckets - 1].  shift >= 43
+ * (2^(52 - shift) <= 512 buckets per binade), so the shifted bit pattern of any double fits
+ * 32 bits with room to spare: the subtraction and the clamp are 32-bit operations (a
+ * 64-bit clamp is two 64-bit compares and four selects per lookup). */
+__device__ __forceinline__ int cs_bucket(double energy, int shift, long long base, int nbuckets) {
+  const int raw = (int)(__double_as_longlong(energy) >> shift) - (int)base;
+  const int top = nbuckets - 1;
+  return (raw < 0) ? 0 : ((raw > top) ? top : raw);
+}
+
 template <typename IndexPtr>
 __device__ __forceinline__ int cs_bracket_indexed(const double* __restrict__ keys, int n,
                                                   IndexPtr start, int nbuckets, int shift,
                                                   long long base, double energy) {
-  long long b = (__double_as_longlong(energy) >> shift) - base;
-  b = (b < 0) ? 0 : ((b > nbuckets - 1) ? nbuckets - 1 : b);
+  const int b = cs_bucket(energy, shift, base, nbuckets);
   int lo = start[b];
   int hi = start[b + 1] + 1;
   hi = (hi > n - 1) ? n - 1 : hi;

@@ -265,8 +265,7 @@ __device__ __forceinline__ BracketSearch bracket_begin(const double* __restrict_
                                                        long long base, double energy) {
   BracketSearch s;
   if (index) {
-    long long b = (__double_as_longlong(energy) >> shift) - base;
-    b = (b < 0) ? 0 : ((b > index_n - 1) ? index_n - 1 : b);
+    const int b = cs_bucket(energy, shift, base, index_n);
     s.lo = index[b];
     s.hi = index[b + 1] + 1;
     s.hi = (s.hi > n - 1) ? n - 1 : s.hi;
