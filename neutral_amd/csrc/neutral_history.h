@@ -68,7 +68,7 @@ struct History {
    * fixed between two reflections, so a crossing is one 8-byte load and one addition per
    * axis -- no direction test, no select. */
   double target_adj_x, target_adj_y;
-  int target_ix, target_iy; /* indices into the edge arrays as the kernel sees them */
+  int target_ix, target_iy; /* edge numbers, counted over the whole mesh */
   /* ... and where a crossing leads (omp3/neutral.c:333-369), also fixed between two
    * reflections: the cell index moves by step (+1, -1; 0 for a direction cosine of exactly
    * zero, which crosses nothing on that axis) unless the history is in the wall cell (the
@@ -182,6 +182,9 @@ struct WindowCellTallyT {
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */
   __device__ __forceinline__ bool inside() const { return (lx < (unsigned)W) & (ly < (unsigned)W); }
+  /* (its own comparison, not !inside(): a wave-wide "any lane outside?" on the negation of
+   * a comparison goes through a vector register; on a comparison it is its lane mask) */
+  __device__ __forceinline__ bool outside() const { return (lx >= (unsigned)W) | (ly >= (unsigned)W); }
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
     if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
@@ -728,8 +731,8 @@ __device__ __forceinline__ bool next_is_facet(History& h) {
 __device__ __forceinline__ void aim_targets(History& h, const SolveArgs& a) {
   const bool up_x = (h.omega_x >= 0.0); /* omp3/neutral.c:438-447 */
   const bool up_y = (h.omega_y >= 0.0);
-  h.target_ix = h.cellx - a.x_off + a.pad + (up_x ? 1 : 0);
-  h.target_iy = h.celly - a.y_off + a.pad + (up_y ? 1 : 0);
+  h.target_ix = h.cellx + (up_x ? 1 : 0);
+  h.target_iy = h.celly + (up_y ? 1 : 0);
   h.target_adj_x = up_x ? -0.0 : -kOpenBoundCorrection;
   h.target_adj_y = up_y ? -0.0 : -kOpenBoundCorrection;
   h.step_x = (h.omega_x > 0.0) ? 1 : ((h.omega_x < 0.0) ? -1 : 0);
@@ -738,7 +741,8 @@ __device__ __forceinline__ void aim_targets(History& h, const SolveArgs& a) {
   h.wall_y = (h.omega_y > 0.0) ? a.global_ny - 1 : ((h.omega_y < 0.0) ? 0 : -1);
 }
 
-/* Edge `index` of an axis (an index into the edge array as the kernel sees it): loaded, or
+/* Edge number `index` of an axis (counted over the whole mesh, as cells are: the offset into
+ * the array this rank sees goes into the array's base, on the scalar unit): loaded, or
  * -- kComputed: the device has checked this step that the formula reproduces the array --
  * worked out: one conversion and one multiplication, rounded as the host's were (never
  * contracted into the addition that follows), and no load for the trip to wait for. */
@@ -753,13 +757,13 @@ __device__ __forceinline__ double edge_from_formula(double spacing, int number) 
 }
 template <bool kComputed>
 __device__ __forceinline__ double edge_x(const SolveArgs& a, int index) {
-  return kComputed ? edge_from_formula(a.edge_dx, index + a.x_off - a.pad)
-                   : *mesh_element(a.edgex, index);
+  return kComputed ? edge_from_formula(a.edge_dx, index)
+                   : *mesh_element(a.edgex + (a.pad - a.x_off), index);
 }
 template <bool kComputed>
 __device__ __forceinline__ double edge_y(const SolveArgs& a, int index) {
-  return kComputed ? edge_from_formula(a.edge_dy, index + a.y_off - a.pad)
-                   : *mesh_element(a.edgey, index);
+  return kComputed ? edge_from_formula(a.edge_dy, index)
+                   : *mesh_element(a.edgey + (a.pad - a.y_off), index);
 }
 
 /* the targets of the history's cell and direction, from the edge arrays */
@@ -911,10 +915,25 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   bool reflect;
   int ncellx, ncelly;
   if (kCarryTargets) {
-    /* (History::step_x ...: the direction tests were made when the history last turned) */
+    /* (History::step_x ...: the direction tests were made when the history last turned)
+     * The axis that moves is picked first, with selects on 32-bit values: written as
+     * logic on the two axes' booleans it comes out as 0/1 values in vector registers
+     * combined by and / compare / select again -- 25 vector instructions where these
+     * are 9. */
+#if defined(NEUTRAL_NO_AXIS_SELECT)
     reflect = xf ? (h.cellx == h.wall_x) : (h.celly == h.wall_y);
     ncellx = h.cellx + ((xf & !reflect) ? h.step_x : 0);
     ncelly = h.celly + ((!xf & !reflect) ? h.step_y : 0);
+#else
+    const int cell = xf ? h.cellx : h.celly;
+    const int wall = xf ? h.wall_x : h.wall_y;
+    reflect = (cell == wall);
+    const int along = xf ? h.step_x : h.step_y;
+    const int step = reflect ? 0 : along;
+    const int dx = xf ? step : 0;
+    ncellx = h.cellx + dx;
+    ncelly = h.celly + (step - dx);
+#endif
   } else {
     const double omega = xf ? h.omega_x : h.omega_y;
     const int cell = xf ? h.cellx : h.celly;
@@ -941,8 +960,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     int ey = h.target_iy;
     if (kDomain == 1 || (kDomain == 2 && a.decomposed)) {
       /* (the neighbour may be another rank's cell: any edge of ours; the history stops) */
-      ex = (ex < 0) ? 0 : ((ex > a.nx + 2 * a.pad) ? a.nx + 2 * a.pad : ex);
-      ey = (ey < 0) ? 0 : ((ey > a.ny + 2 * a.pad) ? a.ny + 2 * a.pad : ey);
+      const int ex_lo = a.x_off - a.pad, ex_hi = a.x_off + a.nx + a.pad;
+      const int ey_lo = a.y_off - a.pad, ey_hi = a.y_off + a.ny + a.pad;
+      ex = (ex < ex_lo) ? ex_lo : ((ex > ex_hi) ? ex_hi : ex);
+      ey = (ey < ey_lo) ? ey_lo : ((ey > ey_hi) ? ey_hi : ey);
     }
 #if defined(NEUTRAL_EXP_NO_EDGE_LOADS)
     /* timing experiment only (uniform meshes): the edges worked out, not loaded */
@@ -1011,6 +1032,14 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 
   h.x += distance_to_facet * h.omega_x;
   h.y += distance_to_facet * h.omega_y;
+  if (kCarryTargets) {
+    /* the position is final before the (rare) reflection turns the direction round: sunk
+     * below that branch, old and new direction are both live across it and every trip of
+     * the facet loop pays four 64-bit register copies for the one in a thousand that turns */
+#if !defined(NEUTRAL_NO_POSITION_PIN)
+    asm volatile("" : "+v"(h.x), "+v"(h.y));
+#endif
+  }
 
   /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
    * division are sign-symmetric), so omp3/neutral.c:435-436 needs no divide here */
@@ -1052,7 +1081,13 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
      * that order), and pinned there */
     calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv, h.target_x, h.target_y,
                              h.distance, h.x_facet);
+#if defined(NEUTRAL_PIN_X_FACET)
     asm volatile("" : "+v"(h.distance), "+v"(h.x_facet));
+#else
+    /* (x_facet is not pinned with it: the comparison's lane mask serves the next trip's
+     * selects as it is -- pinned, it is a 0/1 vector register and a compare per trip) */
+    asm volatile("" : "+v"(h.distance));
+#endif
   }
 
   /* pin the two quotients above the wait for the density: left alone, the compiler

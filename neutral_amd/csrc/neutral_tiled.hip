@@ -687,6 +687,15 @@ __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window,
   }
 }
 
+/* more than kMigrateMinFacets facets ahead of it before the census, at the rate its
+ * direction crosses cells? */
+__device__ __forceinline__ bool far_to_go(const History& h, const TiledArgs& t) {
+  const double ahead = h.speed * h.dt_to_census;
+  const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
+                                       fabs(h.omega_y) * t.cells_per_y);
+  return facets_ahead > kMigrateMinFacets;
+}
+
 template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
@@ -874,7 +883,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
          * ~100 scalar instructions; histories cross ~60 facets in a row), or the
          * end of the history */
         if (h.ev == kEvFacet) {
-          int crossed = kStreamRepeat; /* facets this lane crosses in this pass */
+          int crossed = 0; /* facets this lane crosses in this pass */
+          /* (the compiler merges it with the loop's own trip count, which makes the exit test
+           * a vector compare: three vector instructions per trip.  Kept apart from it -- an
+           * opaque start -- it is one more live register than the loop has: scratch doubles
+           * and every trip copies half the history, profiles/r03/experiments/facet_trip_isa.md) */
           /* the facet loop, compiled twice: for a window whose cells -- and the ring of cells
            * around it -- all hold one density (no density load, no compare while the history
            * is inside it: WindowCellTallyT<, true>), and for any other */
@@ -889,26 +902,28 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             const WindowCellTallyT<kFlux, kUniform> cell_tally{
                 tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
                 (unsigned)(h.celly - a.y_off - tally.oy)};
-            const bool in_window = (cell_tally.lx < (unsigned)kW) & (cell_tally.ly < (unsigned)kW);
-            if (windowed && t.allow_migrate && !in_window) {
-              const double ahead = h.speed * h.dt_to_census;
-              const double facets_ahead = ahead * (fabs(h.omega_x) * t.cells_per_x +
-                                                   fabs(h.omega_y) * t.cells_per_y);
-              leave = facets_ahead > kMigrateMinFacets;
+            const bool out_of_window = cell_tally.outside();
+            /* (wave-uniform test first: most trips have every lane inside the window, and
+             * the four operations below issue whether a lane wants them or not) */
+            if (windowed && t.allow_migrate && __builtin_amdgcn_ballot_w64(out_of_window) != 0) {
+#if !defined(NEUTRAL_NO_LEAVE_BRANCH)
+              asm volatile(""); /* (keeps this a branch the wave takes or skips) */
+#endif
+              if (out_of_window) {
+                leave = far_to_go(h, t);
+              }
             }
             if (leave) {
-              park = kRecMigrate;
-              crossed = rep;
-              break;
+              break; /* (why is worked out again below, once: nothing per trip records it) */
             }
             /* (tallies the cell it leaves: this one) */
             cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
+            ++crossed; /* (one add: `rep + 1` where a lane leaves is a move and a select per trip) */
             if (kDomain) {
               /* the neighbour cell may belong to another rank: the history stops on the
                * facet, before anything of that cell (edges, density) is looked at */
               if (outside_domain(h, a)) {
                 park = kRecEmigrate;
-                crossed = rep + 1;
                 break;
               }
             }
@@ -922,7 +937,6 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               goes_on = (h.ev == kEvFacet);
               park = (h.ev == kEvCollision) ? (int)kRecCollide : park;
             }
-            crossed = goes_on ? crossed : rep + 1;
             if (!goes_on) {
               break;
             }
@@ -948,6 +962,17 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
              * state the loop left: the comparisons next_is_facet() made, with names */
             decide_carried(h);
             park = (park == kRecIdle && h.ev == kEvCollision) ? (int)kRecCollide : park;
+          }
+          /* a history that stopped in front of a facet, outside the window and with far to
+           * go, moves on to the pass that centres a window on it: the one that left the loop
+           * for that reason, and the one the loop's trip count stopped (it would leave on
+           * the next pass's first trip) */
+          if (windowed && t.allow_migrate && park == kRecIdle && h.ev == kEvFacet) {
+            const unsigned lx = (unsigned)(h.cellx - a.x_off - tally.ox);
+            const unsigned ly = (unsigned)(h.celly - a.y_off - tally.oy);
+            if (!((lx < (unsigned)kW) & (ly < (unsigned)kW)) && far_to_go(h, t)) {
+              park = kRecMigrate;
+            }
           }
           /* facets are counted, and the event watchdog applied, once per pass (the
            * loop counter is scalar: per facet they cost three vector and half a
