@@ -188,7 +188,10 @@ struct WindowCellTallyT {
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
     if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
-      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + ly * (unsigned)W + lx], v,
+      /* (a power-of-two window: the row and the column share no bit, and saying so -- `|` --
+       * makes the address a shift-or and a shift) */
+      const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
+      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + cell], v,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
       unsafeAtomicAdd(mesh_element(mesh, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
@@ -1022,9 +1025,16 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     h.mfp_to_collision -= quotient_of_physical<kChecked>(distance_to_facet, h.cell_mfp);
     h.dt_to_census -= quotient_of_physical<kChecked>(distance_to_facet, h.speed);
   }
-  h.energy_deposition += deposit(h, distance_to_facet);
-  tally(a, h.cellx, h.celly, h.energy_deposition);
-  h.energy_deposition = 0.0;
+  if (kCarryTargets) {
+    /* the stream kernel: nothing is pending in the accumulator (every facet flushes it and
+     * collisions happen elsewhere; prologue() and resume() start it at zero), and 0 + d is d:
+     * the accumulator stays out of the facet loop's registers */
+    tally(a, h.cellx, h.celly, deposit(h, distance_to_facet));
+  } else {
+    h.energy_deposition += deposit(h, distance_to_facet);
+    tally(a, h.cellx, h.celly, h.energy_deposition);
+    h.energy_deposition = 0.0;
+  }
   if (Tally::kFlux) {
     tally.flux(a, h.cellx, h.celly, h.track_length + h.weight * distance_to_facet);
     h.track_length = 0.0;

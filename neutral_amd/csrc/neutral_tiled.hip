@@ -687,6 +687,21 @@ __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window,
   }
 }
 
+/* bytes of the stream kernel's dynamic LDS in front of its control words: the window(s),
+ * the staged cs index(es), rounded up to 16 */
+template <bool kSameTables>
+__host__ __device__ __forceinline__ size_t stream_lds_payload_bytes(const SolveArgs& a, int window_cells) {
+  size_t lds = sizeof(double) * (size_t)window_cells;
+  if (a.scatter_index) {
+    lds += sizeof(unsigned short) * (size_t)(a.scatter_index_n + 1);
+  }
+  if (!kSameTables && a.absorb_index) {
+    lds += sizeof(unsigned short) * (size_t)(a.absorb_index_n + 1);
+  }
+  return (lds + 15) & ~(size_t)15;
+}
+constexpr size_t kStreamLdsControlBytes = 32;
+
 /* more than kMigrateMinFacets facets ahead of it before the census, at the rate its
  * direction crosses cells? */
 __device__ __forceinline__ bool far_to_go(const History& h, const TiledArgs& t) {
@@ -703,11 +718,16 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   extern __shared__ double lds_raw[];
   double* window = lds_raw;                                             /* kWindows * kW^2 f64 */
   unsigned short* lds_index = (unsigned short*)(lds_raw + kWindows * kW * kW);
-  __shared__ int s_chunk;
-  __shared__ int s_end;
-  __shared__ int s_tile;
-  __shared__ int s_windowed;
-  __shared__ int s_cursor;
+  /* the workgroup's chunk bookkeeping lives BEHIND the window and the indexes, not in static
+   * LDS in front of them: the window then starts at LDS address 0 and a cell's address is a
+   * shift and a shift-add, without the add of the static variables' size (one vector
+   * instruction per facet) */
+  int* const lds_ctl = (int*)((char*)lds_raw + stream_lds_payload_bytes<kSameTables>(a, kWindows * kW * kW));
+  int& s_chunk = lds_ctl[0];
+  int& s_end = lds_ctl[1];
+  int& s_tile = lds_ctl[2];
+  int& s_windowed = lds_ctl[3];
+  int& s_cursor = lds_ctl[4];
 
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
@@ -895,7 +915,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
 #pragma unroll 1
-          for (int rep = 0; rep < kStreamRepeat; ++rep) {
+          for (;;) {
             /* outside the window with a long way to go: continue in the pass that
              * centres a window on wherever the particle is by then */
             bool leave = false;
@@ -918,7 +938,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
             /* (tallies the cell it leaves: this one) */
             cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
-            ++crossed; /* (one add: `rep + 1` where a lane leaves is a move and a select per trip) */
+            /* (counted in place, by hand: written as ++crossed the compiler compares the old
+             * value, adds into a new register and copies it back -- three instructions) */
+            asm("v_add_u32_e32 %0, 1, %0" : "+v"(crossed));
             if (kDomain) {
               /* the neighbour cell may belong to another rank: the history stops on the
                * facet, before anything of that cell (edges, density) is looked at */
@@ -937,7 +959,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               goes_on = (h.ev == kEvFacet);
               park = (h.ev == kEvCollision) ? (int)kRecCollide : park;
             }
-            if (!goes_on) {
+            /* (`crossed` is the trip count too: every lane in the loop started with it) */
+            if (!goes_on | (crossed >= kStreamRepeat)) {
               break;
             }
           }
@@ -1273,15 +1296,10 @@ hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, 
 /* ---- launcher ---------------------------------------------------------------------- */
 
 size_t tiled_lds_bytes(const SolveArgs& a) {
-  size_t lds = a.flux_tally ? sizeof(double) * 2 * kWindowCellsWithFlux * kWindowCellsWithFlux
-                            : sizeof(double) * kWindow * kWindow;
-  if (a.scatter_index) {
-    lds += sizeof(unsigned short) * (a.scatter_index_n + 1);
-  }
-  if (!a.same_tables && a.absorb_index) {
-    lds += sizeof(unsigned short) * (a.absorb_index_n + 1);
-  }
-  return (lds + 15) & ~(size_t)15;
+  const int cells = a.flux_tally ? 2 * kWindowCellsWithFlux * kWindowCellsWithFlux : kWindow * kWindow;
+  return (a.same_tables ? stream_lds_payload_bytes<true>(a, cells)
+                        : stream_lds_payload_bytes<false>(a, cells)) +
+         kStreamLdsControlBytes;
 }
 
 int tiled_chunk_particles(int nparticles, int compute_units) {
