@@ -82,6 +82,9 @@ struct History {
   /* the decision taken at the loop head */
   double cell_mfp, distance;
   int x_facet;
+  /* stream kernel: the lanes whose next facet is an x facet, as the comparison left them
+   * (wave-uniform: lives in scalar registers; lanes outside the facet loop do not look) */
+  unsigned long long m_x_facet;
   int ev;
 };
 
@@ -181,13 +184,19 @@ struct WindowCellTallyT {
   static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */
-  __device__ __forceinline__ bool inside() const { return (lx < (unsigned)W) & (ly < (unsigned)W); }
+  /* the lanes of the wave whose cell is outside the window (the caller's ballot of
+   * outside()): zero on most trips, and then the add below is the LDS add alone, without
+   * the exec-mask bookkeeping of a two-sided branch */
+  unsigned long long m_outside;
+  /* (from the one comparison the mask was made of: asked again as lx < W & ly < W the
+   * compiler compares again, once per use) */
+  __device__ __forceinline__ bool inside() const { return __builtin_amdgcn_inverse_ballot_w64(~m_outside); }
   /* (its own comparison, not !inside(): a wave-wide "any lane outside?" on the negation of
    * a comparison goes through a vector register; on a comparison it is its lane mask) */
   __device__ __forceinline__ bool outside() const { return (lx >= (unsigned)W) | (ly >= (unsigned)W); }
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
-    if ((lx < (unsigned)W) & (ly < (unsigned)W)) {
+    if (inside()) {
       /* (a power-of-two window: the row and the column share no bit, and saying so -- `|` --
        * makes the address a shift-or and a shift) */
       const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
@@ -914,8 +923,9 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
    * selects: the branch ladder of the reference costs ~35 scalar instructions of
    * exec-mask bookkeeping per facet, and the stream kernel issues 0.7 scalar
    * instructions per vector instruction as it is */
-  const bool xf = (h.x_facet != 0);
+  const bool xf = kCarryTargets ? __builtin_amdgcn_inverse_ballot_w64(h.m_x_facet) : (h.x_facet != 0);
   bool reflect;
+  unsigned long long m_reflect = 0; /* kCarryTargets: the lanes that reflect */
   int ncellx, ncelly;
   if (kCarryTargets) {
     /* (History::step_x ...: the direction tests were made when the history last turned)
@@ -927,6 +937,17 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     reflect = xf ? (h.cellx == h.wall_x) : (h.celly == h.wall_y);
     ncellx = h.cellx + ((xf & !reflect) ? h.step_x : 0);
     ncelly = h.celly + ((!xf & !reflect) ? h.step_y : 0);
+#elif !defined(NEUTRAL_NO_LANE_MASKS)
+    /* ... or the logic is done where it is free: the comparisons' lane masks are combined
+     * on the scalar unit and come back as select conditions (two compares and two selects
+     * in the vector unit) */
+    const unsigned long long m_xf = h.m_x_facet;
+    const unsigned long long m_wall_x = __builtin_amdgcn_ballot_w64(h.cellx == h.wall_x);
+    const unsigned long long m_wall_y = __builtin_amdgcn_ballot_w64(h.celly == h.wall_y);
+    m_reflect = (m_xf & m_wall_x) | (~m_xf & m_wall_y);
+    reflect = __builtin_amdgcn_inverse_ballot_w64(m_reflect);
+    ncellx = h.cellx + (__builtin_amdgcn_inverse_ballot_w64(m_xf & ~m_wall_x) ? h.step_x : 0);
+    ncelly = h.celly + (__builtin_amdgcn_inverse_ballot_w64(~m_xf & ~m_wall_y) ? h.step_y : 0);
 #else
     const int cell = xf ? h.cellx : h.celly;
     const int wall = xf ? h.wall_x : h.wall_y;
@@ -1058,7 +1079,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   if (kCarryTargets) {
     h.cellx = ncellx;
     h.celly = ncelly;
-    if (__ballot(reflect) != 0) { /* wave-uniform: most trips of the facet loop skip it */
+#if defined(NEUTRAL_NO_AXIS_SELECT) || defined(NEUTRAL_NO_LANE_MASKS)
+    m_reflect = __builtin_amdgcn_ballot_w64(reflect);
+#endif
+    if (m_reflect != 0) { /* wave-uniform: most trips of the facet loop skip it */
       h.omega_x = flip_x ? -h.omega_x : h.omega_x;
       h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
       h.omega_y = flip_y ? -h.omega_y : h.omega_y;
@@ -1091,6 +1115,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
      * that order), and pinned there */
     calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv, h.target_x, h.target_y,
                              h.distance, h.x_facet);
+    h.m_x_facet = __builtin_amdgcn_ballot_w64(h.x_facet != 0);
 #if defined(NEUTRAL_PIN_X_FACET)
     asm volatile("" : "+v"(h.distance), "+v"(h.x_facet));
 #else

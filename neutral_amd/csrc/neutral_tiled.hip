@@ -911,6 +911,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           /* the facet loop, compiled twice: for a window whose cells -- and the ring of cells
            * around it -- all hold one density (no density load, no compare while the history
            * is inside it: WindowCellTallyT<, true>), and for any other */
+          h.m_x_facet = __builtin_amdgcn_ballot_w64(h.x_facet != 0); /* (decide_carried's) */
+          /* (all lanes or none: the wave-uniform condition as a lane mask) */
+          const unsigned long long may_migrate = (windowed && t.allow_migrate) ? ~0ull : 0ull;
           auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
@@ -919,13 +922,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             /* outside the window with a long way to go: continue in the pass that
              * centres a window on wherever the particle is by then */
             bool leave = false;
-            const WindowCellTallyT<kFlux, kUniform> cell_tally{
+            WindowCellTallyT<kFlux, kUniform> cell_tally{
                 tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
-                (unsigned)(h.celly - a.y_off - tally.oy)};
+                (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
             const bool out_of_window = cell_tally.outside();
+            cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
             /* (wave-uniform test first: most trips have every lane inside the window, and
              * the four operations below issue whether a lane wants them or not) */
-            if (windowed && t.allow_migrate && __builtin_amdgcn_ballot_w64(out_of_window) != 0) {
+            if ((cell_tally.m_outside & may_migrate) != 0) {
 #if !defined(NEUTRAL_NO_LEAVE_BRANCH)
               asm volatile(""); /* (keeps this a branch the wave takes or skips) */
 #endif
