@@ -196,14 +196,21 @@ struct WindowCellTallyT {
   __device__ __forceinline__ bool outside() const { return (lx >= (unsigned)W) | (ly >= (unsigned)W); }
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
-    if (inside()) {
-      /* (a power-of-two window: the row and the column share no bit, and saying so -- `|` --
-       * makes the address a shift-or and a shift) */
-      const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
-      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + cell], v,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    /* (a power-of-two window: the row and the column share no bit, and saying so -- `|` --
+     * makes the address a shift-or and a shift) */
+    const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
+    lds_double* const slot = &window[which * (unsigned)(W * W) + cell];
+    if (__builtin_expect(m_outside == 0, 1)) {
+      /* every lane inside (most trips): the LDS add and nothing else */
+      (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-      unsafeAtomicAdd(mesh_element(mesh, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
+      asm volatile(""); /* (a branch of its own: merged with the one above, every trip pays
+                         * the exec-mask bookkeeping of the two-sided form) */
+      if (inside()) {
+        (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        unsafeAtomicAdd(mesh_element(mesh, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
+      }
     }
   }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,

@@ -917,6 +917,60 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
+#if !defined(NEUTRAL_TWO_EXIT_FACET_LOOP)
+          if (kCarryTargets) {
+            /* One exit, at the bottom.  "Outside the window with a long way to go: continue in
+             * the pass that centres a window on wherever the particle is by then" is asked
+             * about the cell a crossing ENTERS, together with "is the next event another
+             * facet" -- before the first trip for the cell the history starts in -- so a trip
+             * has one place where lanes leave, and the window coordinates of the new cell are
+             * worked out once: for that question and for the next trip's tally. */
+            WindowCellTallyT<kFlux, kUniform> cell_tally{
+                tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
+                (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
+            bool out_of_window = cell_tally.outside();
+            cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
+            bool run = true;
+            if ((cell_tally.m_outside & may_migrate) != 0) {
+              asm volatile(""); /* (a branch the wave takes or skips, not a predicated block) */
+              if (out_of_window) {
+                run = !far_to_go(h, t);
+              }
+            }
+            if (run) {
+#pragma unroll 1
+              do {
+                /* (tallies the cell it leaves: this one) */
+                cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
+                /* (counted in place, by hand: written as ++crossed the compiler compares the
+                 * old value, adds into a new register and copies it back) */
+                asm("v_add_u32_e32 %0, 1, %0" : "+v"(crossed));
+                if (kDomain) {
+                  /* the neighbour cell may belong to another rank: the history stops on the
+                   * facet, before anything of that cell (edges, density) is looked at */
+                  if (outside_domain(h, a)) {
+                    park = kRecEmigrate;
+                    break;
+                  }
+                }
+                cell_tally.lx = (unsigned)(h.cellx - a.x_off - tally.ox);
+                cell_tally.ly = (unsigned)(h.celly - a.y_off - tally.oy);
+                out_of_window = cell_tally.outside();
+                cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
+                /* (what ends the flight is named below the loop, once; `crossed` is the trip
+                 * count too: every lane in the loop started with it) */
+                run = next_is_facet(h) & (crossed < kStreamRepeat);
+                if ((cell_tally.m_outside & may_migrate) != 0) {
+                  asm volatile("");
+                  if (out_of_window) {
+                    run = run & !far_to_go(h, t);
+                  }
+                }
+              } while (run);
+            }
+            return;
+          }
+#endif
 #pragma unroll 1
           for (;;) {
             /* outside the window with a long way to go: continue in the pass that
