@@ -24,15 +24,18 @@ BUILD = os.path.join(ROOT, "neutral_amd", "build")
 TARGETS = {
     "collide": ("neutral_kernels-hip-amdgcn-amd-amdhsa-gfx950.s",
                 "_ZN7neutral22history_regroup_kernelILb1ELb1ELb0ELb0EEEvNS_9SolveArgsE",
-                r"v_alignbit_b32", 60, None, 0),
-    # the facet loop is compiled twice (neutral_tiled.hip: run_facets): for windows of one
-    # density (no density load in the trip) and for any other
+                r"v_alignbit_b32", 60, None),
+    # the facet loop is compiled four times (neutral_tiled.hip: run_facets).  Two are priced: for
+    # windows of one density (no density load in the trip) and for any other, both with the
+    # edges computed.  A loop is recognised by the cross_facet instantiation inlined into it
+    # (the compiler names it in the block comments): <kChecked=0, kCachedReciprocals=1,
+    # kDomain=0, kCarryTargets=1, kComputedEdges=1, WindowCellTallyT<flux=0, uniform=0|1>>
     "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
               "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-              r"v_mul_f64", 12, r"v_cmp_ne_u64", 1),
+              r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb0EEE"),
     "facet_uniform": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
                       "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-                      r"v_mul_f64", 12, r"v_cmp_ne_u64", 0),
+                      r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb1EEE"),
 }
 
 # Issue cycles one wave64 instruction holds its SIMD for, by opcode, measured with
@@ -107,21 +110,39 @@ def loops(items):
     return out
 
 
-def hot_loop(items, marker, min_marker, also=None, also_min=0):
-    """the smallest loop with min_marker `marker` opcodes; `also`: it must (also_min = 1) or
-    must not (0) hold that opcode too -- the density compare tells the two facet loops apart"""
+def hot_loop(items, marker, min_marker, named=None):
+    """the smallest loop with min_marker `marker` opcodes; `named`: one of its block labels
+    must carry that text in its comment (the inlined function the block came from)"""
     best = None
     for a, b in loops(items):
         n = sum(1 for _, op, _ in items[a:b + 1] if op and re.match(marker, op))
-        if also is not None:
-            m = sum(1 for _, op, _ in items[a:b + 1] if op and re.match(also, op))
-            if (m >= 1) != (also_min >= 1):
-                continue
+        if named is not None and not any(lab and named in text for lab, _, text in items[a:b + 1]):
+            continue
         if n >= min_marker and (best is None or (b - a) < (best[1] - best[0])):
             best = (a, b)
     if best is None:
         raise SystemExit("no loop with the marker found")
     return best
+
+
+def hot_path(span, rare_min=8):
+    """the trip without its rare sides: a run of instructions a conditional branch jumps over
+    (forward, inside the loop) that holds more than rare_min vector instructions is a path the
+    common trip skips -- in the facet loop: the reflection, the change of density, the
+    question whether a history outside the window waits for the next pass, the tally of a
+    cell outside the window.  (The common trip's own conditional runs are a handful of
+    instructions: the LDS add.)"""
+    pos = {lab: k for k, (lab, _, _) in enumerate(span) if lab}
+    drop = [False] * len(span)
+    for k, (_, op, text) in enumerate(span):
+        if op and op.startswith("s_cbranch"):
+            m = re.search(r"(\.LBB\d+_\d+)", text)
+            if m and m.group(1) in pos and pos[m.group(1)] > k:
+                j = pos[m.group(1)]
+                if sum(1 for _, o, _ in span[k + 1:j] if o and o.startswith("v_")) > rare_min:
+                    for i in range(k + 1, j):
+                        drop[i] = True
+    return [it for it, d in zip(span, drop) if not d]
 
 
 def main():
@@ -143,10 +164,13 @@ def main():
                   f"mean {m['mean_cycles_per_valu']:.3f} ({m['mean_cycles_per_valu_low']:.3f}-"
                   f"{m['mean_cycles_per_valu_high']:.3f})")
         return
-    fname, symbol, marker, min_marker, also, also_min = TARGETS[args.target]
+    fname, symbol, marker, min_marker, named = TARGETS[args.target]
     items = parse(function_body(os.path.join(BUILD, fname), symbol))
-    a, b = hot_loop(items, marker, min_marker, also, also_min)
+    a, b = hot_loop(items, marker, min_marker, named)
     span = items[a:b + 1]
+    whole_valu = sum(1 for _, op, _ in span if op and op.startswith("v_"))
+    if args.target.startswith("facet"):
+        span = hot_path(span)
     if args.dump:
         for lab, op, text in span:
             print(text)
@@ -171,7 +195,8 @@ def main():
     lo_cycles = cycles - fam_cycles + fam * min(costs.get("v_xor_b32", 2.0), 2.0)
     hi_cycles = cycles - fam_cycles + fam * max(costs.get("v_mad_u64_u32", 4.4), 4.4)
     out = {"target": args.target, "symbol": symbol,
-           "loop": {"first_label": span[0][0], "instructions": sum(1 for _, op, _ in span if op)},
+           "loop": {"first_label": span[0][0], "instructions": sum(1 for _, op, _ in span if op),
+                    "valu_with_rare_paths": whole_valu},
            "valu_instructions": nvalu, "salu_instructions": salu, "memory_instructions": dict(mem),
            "issue_cycles_per_trip": cycles, "mean_cycles_per_valu": cycles / max(nvalu, 1),
            "mean_cycles_per_valu_low": lo_cycles / max(nvalu, 1),
