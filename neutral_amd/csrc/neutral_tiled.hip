@@ -521,6 +521,15 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
     const long long per_sparse =
         ((long long)t.chunk_particles * (long long)t.ntiles + nactive - 1) / (long long)nactive;
     per = (per_sparse > per) ? per_sparse : per;
+    /* (... but no thread sweeps more than kSweepTilesMax tiles: with a few hundred
+     * histories left in a late pass of a sparse deck, one thread walked the whole mesh,
+     * twice, while 1023 waited: 250 us per launch on the shipped csp deck, as long as the
+     * stream kernel it feeds.  The chunks of such a pass are smaller than a chunk, which
+     * costs nothing: they are a wave's worth of work each, on workgroups of their own) */
+    constexpr long long kSweepTilesMax = 32;
+    const long long floor_per = (t.ntiles + 1023) / 1024;
+    const long long cap = (floor_per > kSweepTilesMax) ? floor_per : kSweepTilesMax;
+    per = (per > cap) ? cap : per;
   }
   per = (per > t.ntiles) ? t.ntiles : per;
   const long long lo_ll = (long long)tid * per;
