@@ -95,6 +95,29 @@ def test_meshes_with_more_tiles_than_the_sort_keeps_in_lds(iface, make_problem, 
     assert got[3][0].tile_cells == 16
 
 
+@pytest.mark.parametrize("deck,nx,n,dt,tile", [
+    ("stream", 2048, 3000, None, 16),   # 16 384 tiles, a few hundred histories per late pass
+    ("csp", 1600, 6000, 2.0e-6, 32),    # 2 500 tiles; colliders thin the passes out further
+    ("stream", 4000, 900, None, 128),   # the shipped mesh with fewer particles than tiles
+])
+def test_thin_passes_over_many_tiles(iface, make_problem, cs, monkeypatch, deck, nx, n, dt, tile):
+    """Late passes of a sparse deck hold a few hundred histories spread over thousands of
+    tiles: the chunk list then comes from threads that each sweep a bounded run of tiles
+    (tile_chunks_kernel), as un-windowed chunks much smaller than a chunk.  Same histories
+    as the over-particle kernel, bit for bit."""
+    kw = dict(nx=nx, nparticles=n, iterations=1)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    want = _run(iface, prob, cs, 0, 1)
+    monkeypatch.setenv("NEUTRAL_TILE_CELLS", str(tile))
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "8")
+    got = _run(iface, prob, cs, 2, 1)
+    _same(want, got)
+    assert got[3][0].tile_cells == tile
+    assert got[3][0].aborted == 0
+
+
 def test_tile_edge_follows_the_particle_density(iface, make_problem, cs):
     for deck, nx, n, want in (("csp", 100, 100000, 16), ("csp", 200, 100000, 32),
                               ("csp", 400, 100000, 64), ("stream", 1000, 20000, 128)):
