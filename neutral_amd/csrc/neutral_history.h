@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
 #if defined(NEUTRAL_NO_AXIS_SELECT) || defined(NEUTRAL_NO_LANE_MASKS)
     m_reflect = __builtin_amdgcn_ballot_w64(reflect);
 #endif
-    if (m_reflect != 0) { /* wave-uniform: most trips of the facet loop skip it */
+    if (__builtin_expect(m_reflect != 0, 0)) { /* wave-uniform: most trips of the facet loop skip it */
       h.omega_x = flip_x ? -h.omega_x : h.omega_x;
       h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
       h.omega_y = flip_y ? -h.omega_y : h.omega_y;
@@ -1137,7 +1137,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   asm volatile("" : "+v"(h.mfp_to_collision), "+v"(h.dt_to_census));
 
 #if !defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
-  if (Tally::kUniformDensity) {
+  if constexpr (Tally::kUniformDensity) {
+    if (__builtin_expect(tally.m_outside == 0, 1)) {
+      return; /* (no lane outside the window: asked of the wave first, it is a scalar test) */
+    }
     if (tally.inside()) {
       return; /* the cell entered has the density this history carries */
     }
