@@ -912,11 +912,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
          * ~100 scalar instructions; histories cross ~60 facets in a row), or the
          * end of the history */
         if (h.ev == kEvFacet) {
-          int crossed = 0; /* facets this lane crosses in this pass */
-          /* (the compiler merges it with the loop's own trip count, which makes the exit test
-           * a vector compare: three vector instructions per trip.  Kept apart from it -- an
-           * opaque start -- it is one more live register than the loop has: scratch doubles
-           * and every trip copies half the history, profiles/r03/experiments/facet_trip_isa.md) */
+          /* facets this lane crosses in this pass.  (It is the loop's trip count as well, and
+           * stays the only counter: one kept apart from the compiler's own -- an opaque start
+           * -- is one live register more than the loop has; scratch doubles and every trip
+           * copies half the history, 126 -> 166 vector instructions) */
+          int crossed = 0;
           /* the facet loop, compiled twice: for a window whose cells -- and the ring of cells
            * around it -- all hold one density (no density load, no compare while the history
            * is inside it: WindowCellTallyT<, true>), and for any other */
@@ -926,7 +926,6 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
-#if !defined(NEUTRAL_TWO_EXIT_FACET_LOOP)
           if (kCarryTargets) {
             /* One exit, at the bottom.  "Outside the window with a long way to go: continue in
              * the pass that centres a window on wherever the particle is by then" is asked
@@ -979,7 +978,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
             return;
           }
-#endif
+          /* (the experiment build without carried targets, NEUTRAL_NO_CARRIED_TARGETS: the
+           * loop as it was, with its two exits) */
 #pragma unroll 1
           for (;;) {
             /* outside the window with a long way to go: continue in the pass that
@@ -993,9 +993,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             /* (wave-uniform test first: most trips have every lane inside the window, and
              * the four operations below issue whether a lane wants them or not) */
             if ((cell_tally.m_outside & may_migrate) != 0) {
-#if !defined(NEUTRAL_NO_LEAVE_BRANCH)
               asm volatile(""); /* (keeps this a branch the wave takes or skips) */
-#endif
               if (out_of_window) {
                 leave = far_to_go(h, t);
               }
