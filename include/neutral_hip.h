@@ -193,6 +193,8 @@ typedef struct {
                             together travel with the tally, on the device.  A decomposed mesh
                             counts the rounds of its particle exchange here */
   int exchange_ranks;    /* ranks the last tally exchange summed over (1: no exchange) */
+  uint64_t steals;       /* tiled variant: times a wave of the collision stage that had emptied
+                            its ring took half of what waited in the ring of a wave of its CU */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

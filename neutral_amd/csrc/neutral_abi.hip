@@ -27,7 +27,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 6 /* 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 7 /* 7: NeutralHipStepStats grew steals; 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
@@ -524,6 +524,7 @@ enum StepWord : int {
   kWordQueued = 12,     /* histories this batch's collision stage was handed */
   kWordAborted = 13,
   kWordRanks = 14,      /* 1 per rank: how many ranks the transport summed over */
+  kWordSteals = 15,     /* rings the collision stage's waves took from (see StepCounters) */
   kStepWords = 16,
 };
 
@@ -560,7 +561,7 @@ __global__ void pack_step_words_kernel(const neutral::StepCounters* c, const uns
   w[kWordQueued] = ctrl ? ctrl[2] : 0u;
   w[kWordAborted] = (unsigned long long)c[0].aborted + c[1].aborted;
   w[kWordRanks] = 1ull;
-  w[15] = 0ull;
+  w[kWordSteals] = c[0].nsteals + c[1].nsteals;
 }
 
 __global__ void add_step_tally_kernel(double* __restrict__ tally, const double* __restrict__ step,
@@ -1316,6 +1317,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     hc[1].nrequeued = words[kWordRequeued];
     hc[0].ncollide_passes = 0;
     hc[1].ncollide_passes = words[kWordCollidePasses];
+    hc[0].nsteals = 0;
+    hc[1].nsteals = words[kWordSteals];
     hc[0].aborted = 0;
     hc[1].aborted = (unsigned)words[kWordAborted];
   } else if (neutral::comm_nranks() > 1) {
@@ -1360,6 +1363,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.stream_passes = tiled ? (int)ctrl[5] : 0;
   g.last.requeued = tiled ? hc[1].nrequeued : 0;
   g.last.collide_passes = hc[0].ncollide_passes + hc[1].ncollide_passes;
+  g.last.steals = hc[0].nsteals + hc[1].nsteals;
   g.last.host_syncs = g.host_syncs;
   g.last.stream_passes_enqueued = tiled ? passes : 0;
   g.last.tile_cells = tiled ? (1 << g.tiled.tile_shift) : 0;

@@ -87,6 +87,7 @@ struct StepCounters {
   unsigned int aborted;       /* histories stopped by the event watchdog (should be 0) */
   unsigned long long nrequeued; /* time-slice swaps of the collision stage (queue mode) */
   unsigned long long ncollide_passes; /* wave-level COLLIDE passes of the regroup kernel */
+  unsigned long long nsteals; /* collision stage: rings a wave took half the waiting histories of */
 };
 
 struct SolveArgs {
@@ -155,6 +156,8 @@ struct SolveArgs {
   /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
    * eleven more array pointers (the collision stage): read where a history ends */
   const ParticleView* export_view;
+  int steal_min;              /* collision stage: waiting histories a ring must hold to be taken
+                                 from by a CU-mate (0: no stealing; NEUTRAL_STEAL_MIN) */
   int occupancy_rows;         /* collision stage: workgroups per CU resident together, among
                                  which the kernel picks how many work (0: all) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead

@@ -317,6 +317,54 @@ constexpr int kSliceWindow = NEUTRAL_SLICE_WINDOW;
 constexpr int kPoolMaxShare = NEUTRAL_POOL_MAX_SHARE;
 constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is valid */
 
+/* ---- the waves of a CU finish together: stealing between their rings (pooled mode) ---
+ * A SIMD issues for its OLDEST ready wave first.  With equal shares the oldest of a SIMD's
+ * four waves takes what issue it can use (60 %) and is out after a third of the stage, the
+ * second after two thirds, and the youngest ends the stage ALONE -- where a collider's
+ * dependent table probes are covered by nobody: 2 335 cycles per collision pass in csp
+ * against 2 077 in the decks whose waves draw from one queue and leave together
+ * (profiles/r03/experiments/collision_wave_exit_times.log; s_setprio, turned in rotation or
+ * steered by the waves' progress, does not change the order: same log).  So a wave that
+ * has emptied its ring takes half of what WAITS in the fullest ring of a wave of its own
+ * CU, as often as there is one to take from, and the sixteen waves of a CU end within a
+ * slice of each other with all of them present until then.
+ *   * Who shares a CU is read from the hardware (HW_ID, XCC_ID): every wave enters itself
+ *     in its CU's list at the start of the launch.  Same CU on purpose: a record a wave
+ *     wrote (write-through L1, the CU's own) is seen by its CU-mates after the writer's
+ *     wait for its stores, without the L2 write-back and invalidate an exchange between
+ *     the chip's eight XCDs would need at every slice.
+ *   * A ring's control word (head << 32 | waiting) lives in memory: its owner takes from the
+ *     head by compare-and-swap and appends by an atomic add (the tail -- head + waiting --
+ *     moves only when the owner appends, so it is the owner's own); a thief takes from the
+ *     head by compare-and-swap.  The entries a take frees lie behind the tail by as many
+ *     places as histories left the ring for good, so nobody writes where somebody reads.
+ *   * Histories are independent and carry their whole state in their record (+ SuspendExtra),
+ *     so which wave finishes a history changes nothing it computes. */
+constexpr int kRingCtlSlots = 8192;  /* waves of a launch (4 096 on an MI355X) */
+constexpr int kCuSlots = 4096;       /* (xcc 4 bits, se 3, sh 1, cu 4) */
+constexpr int kCuWavesMax = 16;
+#ifndef NEUTRAL_STEAL_MIN
+#define NEUTRAL_STEAL_MIN 128
+#endif
+constexpr int kStealMin = NEUTRAL_STEAL_MIN; /* waiting histories a ring must hold to be taken from
+                                               (SolveArgs::steal_min; 0: no stealing) */
+__device__ unsigned long long g_ring_ctl[kRingCtlSlots];
+__device__ unsigned g_cu_count[kCuSlots];
+__device__ unsigned g_cu_members[kCuSlots * kCuWavesMax];
+
+__device__ __forceinline__ unsigned cu_key() {
+  /* HW_ID (s_getreg id 4): cu [11:8], sh [12], se [15:13]; XCC_ID (id 20): [3:0] */
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+  return ((hw >> 8) & 0xFFu) | ((xcc & 0xFu) << 8);
+}
+__device__ __forceinline__ unsigned long long ring_ctl_load(int wave) {
+  return __hip_atomic_load(&g_ring_ctl[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned wave_uniform(unsigned v) {
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 
 /* The kernel's arguments, read again from the kernarg segment: for the cold paths of the
  * collision stage (refill, hand-back, facet and census of a stray history, end of a time
@@ -369,6 +417,10 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * colliders mixed (parked lanes make occupancy matter: 4 waves/SIMD, small
  * spill); kQueue = true: the collision stage of the tiled pipeline, histories
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
+#if defined(NEUTRAL_EXP_WAVE_TIMES)
+__device__ unsigned long long g_wave_times[10] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
+#endif
+
 template <bool kSameTables, bool kQueue, bool kFlux, bool kChecked>
 __global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux && !kChecked) ? NEUTRAL_K2_QUEUE_WAVES : 3)
                                              : NEUTRAL_K2_WAVES)
@@ -377,6 +429,10 @@ void history_regroup_kernel(SolveArgs a) {
   unsigned ncollisions = 0;
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
+#if defined(NEUTRAL_EXP_WAVE_TIMES)
+  const unsigned long long exp_t0 = wall_clock64();
+  const unsigned long long exp_c0 = clock64();
+#endif
 
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
@@ -477,12 +533,101 @@ void history_regroup_kernel(SolveArgs a) {
 
   /* pooled mode (the collision stage): the wave's strided share of the queue is its
    * ring; all wave-uniform */
-  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare);
+  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare) &&
+                      nwaves <= kRingCtlSlots;
   const int gw = block_index * (kBlock / 64) + (int)(threadIdx.x >> 6);
   const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
-  int ring_head = 0;      /* ring position of the oldest waiting history, in [0, share) */
-  int ring_count = share; /* histories waiting in the ring */
+  /* the ring's control word is g_ring_ctl[gw] (above); these are the owner's own view */
+  unsigned w_steals = 0;
+  int ring_tail = 0;      /* ring position the next history handed back goes to (head + waiting) */
+  int ring_count = share; /* histories waiting in the ring, as last seen (a CU-mate may have taken some) */
   int slice = 0;
+  const unsigned my_cu = pooled ? cu_key() : 0u;
+  if (pooled && (threadIdx.x & 63) == 0) {
+    g_ring_ctl[gw] = (unsigned long long)(unsigned)share; /* head 0 */
+    if (a.steal_min > 0 && share > 0) {
+      const unsigned slot = atomicAdd(&g_cu_count[my_cu], 1u);
+      if (slot < (unsigned)kCuWavesMax) {
+        g_cu_members[my_cu * kCuWavesMax + slot] = (unsigned)gw;
+      }
+    }
+  }
+  /* a wave whose ring is empty and whose lanes are idle: half of what waits in the fullest
+   * ring of its CU, if that is worth taking (all wave-uniform) */
+  auto try_steal = [&]() -> bool {
+    /* (small shares -- a hundred histories per wave, the 8-GPU share of csp -- are better left
+     * alone: what a thief takes there it runs in half-empty passes that the SIMD issues ahead
+     * of its younger CU-mates' full ones; 48.5 against 46.5 ms per 10 steps) */
+    const unsigned steal_min = (unsigned)a.steal_min;
+    if (!pooled || steal_min == 0 || (unsigned)share < 2u * steal_min) {
+      return false;
+    }
+    const int lane = (int)(threadIdx.x & 63);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      unsigned mates = __hip_atomic_load(&g_cu_count[my_cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mates = (mates > (unsigned)kCuWavesMax) ? (unsigned)kCuWavesMax : mates;
+      unsigned victim = 0;
+      unsigned long long ctl = 0;
+      if ((unsigned)lane < mates) {
+        victim = __hip_atomic_load(&g_cu_members[my_cu * kCuWavesMax + lane], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        /* (the launch starts with every entry invalid; a mate that has only counted itself
+         * in so far is not looked at) */
+        if (victim < (unsigned)nwaves && (int)victim != gw) {
+          ctl = ring_ctl_load((int)victim);
+        }
+      }
+      unsigned waiting = (unsigned)ctl;
+      unsigned best = waiting;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        const unsigned other = __shfl_xor(best, off, 64);
+        best = (other > best) ? other : best;
+      }
+      best = wave_uniform(best); /* (the maximum over lanes 0..15, in lane 0) */
+      if (best < steal_min || best < 2u) {
+        return false;
+      }
+      const unsigned long long m_best = __ballot((unsigned)lane < mates && waiting == best);
+      const int src = __builtin_ctzll(m_best);
+      const int v = (int)__shfl(victim, src, 64);
+      const unsigned v_head = (unsigned)__shfl((unsigned)(ctl >> 32), src, 64);
+      const int v_share = (nwork - v + nwaves - 1) / nwaves;
+      unsigned take = best / 2u;
+      take = (take > (unsigned)share) ? (unsigned)share : take;
+      unsigned new_head = v_head + take;
+      new_head = (new_head >= (unsigned)v_share) ? new_head - (unsigned)v_share : new_head;
+      unsigned won = 0;
+      if (lane == 0) {
+        const unsigned long long seen = ((unsigned long long)v_head << 32) | best;
+        const unsigned long long next = ((unsigned long long)new_head << 32) | (best - take);
+        won = (atomicCAS(&g_ring_ctl[v], seen, next) == seen) ? 1u : 0u;
+      }
+      if (!wave_uniform(won)) {
+        continue; /* (its owner or another CU-mate was quicker: look again) */
+      }
+      /* the entries [v_head, v_head + take) of v's ring are this wave's now */
+      for (unsigned i = (unsigned)lane; i < take; i += 64u) {
+        unsigned pos = v_head + i;
+        pos = (pos >= (unsigned)v_share) ? pos - (unsigned)v_share : pos;
+        const unsigned e = __hip_atomic_load(a.queue + ((size_t)v + (size_t)pos * (size_t)nwaves),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.queue[(size_t)gw + (size_t)i * (size_t)nwaves] = e; /* this wave's ring, from position 0 */
+      }
+      __threadfence_block();
+      if (lane == 0) {
+        atomicExch(&g_ring_ctl[gw], (unsigned long long)take); /* head 0, `take` waiting */
+      }
+      ring_tail = ((int)take >= share) ? (int)take - share : (int)take;
+      ring_count = (int)take;
+      w_steals++;
+#if defined(NEUTRAL_EXP_WAVE_TIMES)
+      if (lane == 0) atomicAdd(&g_wave_times[8], 1ull);
+#endif
+      return true;
+    }
+    return false;
+  };
   unsigned w_requeued = 0;
   unsigned w_collide_passes = 0;
   /* ring position -> queue entry (pos < 2 * share) */
@@ -501,6 +646,10 @@ void history_regroup_kernel(SolveArgs a) {
     const int n_stream = __popcll(m_stream);
     const int n_collide = __popcll(m_collide);
     if (n_refill + n_stream + n_collide == 0) {
+      if (kQueue && drained && try_steal()) {
+        drained = false;
+        continue;
+      }
       break;
     }
 
@@ -540,7 +689,30 @@ void history_regroup_kernel(SolveArgs a) {
 
     if (pass == kWantRefill && pooled) {
       /* ---- REFILL pass, pooled: the histories at the front of the ring ---- */
-      const int n_take = (n_refill < ring_count) ? n_refill : ring_count;
+      unsigned taken = 0, head_was = 0, left = 0;
+      if ((threadIdx.x & 63) == 0) {
+        unsigned long long seen = ring_ctl_load(gw);
+        for (;;) {
+          const unsigned waiting = (unsigned)seen;
+          head_was = (unsigned)(seen >> 32);
+          taken = ((unsigned)n_refill < waiting) ? (unsigned)n_refill : waiting;
+          left = waiting - taken;
+          if (taken == 0) {
+            break;
+          }
+          unsigned nh = head_was + taken;
+          nh = (nh >= (unsigned)share) ? nh - (unsigned)share : nh;
+          const unsigned long long next = ((unsigned long long)nh << 32) | left;
+          const unsigned long long old = atomicCAS(&g_ring_ctl[gw], seen, next);
+          if (old == seen) {
+            break;
+          }
+          seen = old; /* (a CU-mate took from the head meanwhile) */
+        }
+      }
+      const int n_take = (int)wave_uniform(taken);
+      const int ring_head = (int)wave_uniform(head_was);
+      ring_count = (int)wave_uniform(left);
       const int rank = lane_rank(m_refill);
       if (want == kWantRefill && rank < n_take) {
         const SolveArgs c = NEUTRAL_COLD_ARGS(a);
@@ -560,9 +732,6 @@ void history_regroup_kernel(SolveArgs a) {
         next_event(true);
         want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
       }
-      ring_head += n_take;
-      ring_head = (ring_head >= share) ? ring_head - share : ring_head;
-      ring_count -= n_take;
       drained = (ring_count == 0);
     } else if (pass == kWantRefill) {
       /* ---- REFILL pass: hand fresh particle ids to the empty lanes ---- */
@@ -674,18 +843,23 @@ void history_regroup_kernel(SolveArgs a) {
             c.susp_track[pid] = h.track_length;
           }
           /* outstanding histories never exceed the share: the slot is free */
-          int back = ring_head + ring_count;
-          back = (back >= share) ? back - share : back;
-          *ring_slot(back + lane_rank(m_out)) = (unsigned)pid | kRequeued;
+          *ring_slot(ring_tail + lane_rank(m_out)) = (unsigned)pid | kRequeued;
           want = kWantRefill;
         }
-        ring_count += __popcll(m_out);
-        w_requeued += (unsigned)__popcll(m_out);
+        const int n_out = __popcll(m_out);
+        w_requeued += (unsigned)n_out;
         drained = false;
-        /* the same wave reads these records and ring words back later, possibly
-         * from another lane: stores complete (workgroup scope: same CU, same L1)
-         * first */
+        /* this wave -- possibly another lane of it -- or a wave of its CU reads these records
+         * and ring words back later: the stores complete first (workgroup scope: same CU,
+         * same L1), THEN the control word says that they wait */
         __threadfence_block();
+        unsigned waiting_before = 0;
+        if ((threadIdx.x & 63) == 0) {
+          waiting_before = (unsigned)atomicAdd(&g_ring_ctl[gw], (unsigned long long)n_out);
+        }
+        ring_count = (int)wave_uniform(waiting_before) + n_out;
+        ring_tail += n_out;
+        ring_tail = (ring_tail >= share) ? ring_tail - share : ring_tail;
       }
     } else {
       /* ---- STREAM pass: facet crossings, census, end of history ---- */
@@ -717,9 +891,42 @@ void history_regroup_kernel(SolveArgs a) {
     }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
+#if defined(NEUTRAL_EXP_WAVE_TIMES)
+  /* timing experiment only: when do the waves of the collision stage run out of work?
+   * (100-MHz wall clock; the last wave out prints first / mean / last exit of the launch) */
+  if (kQueue && (threadIdx.x & 63) == 0 && nwork > 4096) {
+    const unsigned long long now = wall_clock64();
+    const unsigned long long cnow = clock64();
+    if (now - exp_t0 > 100000ull) { /* (waves that lived > 1 ms: shader clocks per 100-MHz tick) */
+      atomicMax(&g_wave_times[7], (cnow - exp_c0) * 1000ull / (now - exp_t0));
+    }
+    atomicMin(&g_wave_times[0], now);
+    atomicMax(&g_wave_times[1], now);
+    atomicAdd(&g_wave_times[2], now - exp_t0);
+    atomicMin(&g_wave_times[4], exp_t0);
+    atomicAdd(&g_wave_times[5], (unsigned long long)w_collide_passes);
+    atomicMax(&g_wave_times[6], (unsigned long long)w_collide_passes);
+    const unsigned long long n = atomicAdd(&g_wave_times[3], 1ull) + 1ull;
+    if (n == (unsigned long long)nwaves) {
+      __threadfence();
+      const unsigned long long t0 = atomicMin(&g_wave_times[4], ~0ull);
+      const unsigned long long first = atomicMin(&g_wave_times[0], ~0ull);
+      const unsigned long long last = atomicMax(&g_wave_times[1], 0ull);
+      printf("collision stage: %d histories on %d waves: first wave out after %.3f ms, mean %.3f, last %.3f; "
+             "passes per wave mean %.0f max %llu; shader clock %.3f GHz; steals %llu\n", nwork, nwaves,
+             (double)(first - t0) * 1e-5, (double)g_wave_times[2] / (double)nwaves * 1e-5,
+             (double)(last - t0) * 1e-5, (double)g_wave_times[5] / (double)nwaves, g_wave_times[6],
+             (double)g_wave_times[7] * 1e-4, g_wave_times[8]);
+      g_wave_times[0] = ~0ull; g_wave_times[1] = 0; g_wave_times[2] = 0; g_wave_times[3] = 0;
+      g_wave_times[4] = ~0ull; g_wave_times[5] = 0; g_wave_times[6] = 0; g_wave_times[7] = 0;
+      g_wave_times[8] = 0;
+    }
+  }
+#endif
   if ((threadIdx.x & 63) == 0) {
     if (w_ncollisions) atomicAdd(&a.counters->ncollisions, w_ncollisions);
     if (w_requeued) atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
+    if (w_steals) atomicAdd(&a.counters->nsteals, (unsigned long long)w_steals);
     if (w_collide_passes) {
       atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
     }
@@ -1117,6 +1324,35 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       }
       if (a.max_blocks > 0 && grid > a.max_blocks) {
         grid = a.max_blocks;
+      }
+      {
+        /* (tests: a collision stage of a few workgroups gives a test deck's waves shares as
+         * long as a full-size run's) */
+        const char* limit = getenv("NEUTRAL_COLLISION_BLOCKS");
+        if (a.queue && limit && atoi(limit) > 0 && grid > atoi(limit)) {
+          grid = atoi(limit);
+          k.occupancy_rows = 0;
+        }
+      }
+      k.steal_min = kStealMin;
+      {
+        const char* force = getenv("NEUTRAL_STEAL_MIN"); /* (tests: small rings taken from too) */
+        if (force && atoi(force) >= 0) {
+          k.steal_min = atoi(force);
+        }
+      }
+      if (a.queue && k.steal_min > 0) {
+        /* the CU lists of the collision stage's waves start empty (g_cu_count / g_cu_members) */
+        static void* cu_count = nullptr;
+        static void* cu_members = nullptr;
+        if (!cu_count) {
+          (void)hipGetSymbolAddress(&cu_count, HIP_SYMBOL(g_cu_count));
+          (void)hipGetSymbolAddress(&cu_members, HIP_SYMBOL(g_cu_members));
+        }
+        if (cu_count && cu_members) {
+          (void)hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream);
+          (void)hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream);
+        }
       }
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, k);
     };

@@ -68,7 +68,8 @@ class StepStats(C.Structure):
                 ("host_syncs", C.c_int), ("stream_passes_enqueued", C.c_int),
                 ("tile_cells", C.c_int), ("export_ms", C.c_double),
                 ("checked_arithmetic", C.c_int), ("attempts", C.c_int),
-                ("host_collectives", C.c_int), ("exchange_ranks", C.c_int)]
+                ("host_collectives", C.c_int), ("exchange_ranks", C.c_int),
+                ("steals", C.c_uint64)]
 
 
 # every symbol include/neutral_hip.h declares

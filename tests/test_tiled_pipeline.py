@@ -118,6 +118,35 @@ def test_thin_passes_over_many_tiles(iface, make_problem, cs, monkeypatch, deck,
     assert got[3][0].aborted == 0
 
 
+@pytest.mark.parametrize("deck,nx,n,dt,steps", [
+    ("split", 200, 1000000, 5.0e-7, 2),   # every particle collides: 240 histories per wave
+    ("scatter", 200, 800000, None, 1),
+])
+def test_histories_taken_over_by_another_wave(iface, make_problem, cs, monkeypatch, deck, nx, n, dt,
+                                              steps):
+    """A wave of the collision stage that has emptied its ring takes half of what waits in the
+    ring of a wave of its own CU (history_regroup_kernel: try_steal) -- the oldest wave of a
+    SIMD gets most of its issue slots and is through its share long before the others.  By
+    default only rings of hundreds of histories are taken from (1e8-particle runs);
+    NEUTRAL_STEAL_MIN=1 lets the 240 a million-particle deck gives every wave be taken too.
+    Which wave finishes a history changes nothing it computes: same bits as the
+    over-particle kernel, same event counts -- with and without."""
+    kw = dict(nx=nx, nparticles=n, iterations=steps)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    want = _run(iface, prob, cs, 0, steps)
+    monkeypatch.setenv("NEUTRAL_STEAL_MIN", "1")
+    got = _run(iface, prob, cs, 2, steps)
+    _same(want, got)
+    assert sum(s.steals for s in got[3]) > 100
+    assert all(s.aborted == 0 for s in got[3])
+    monkeypatch.setenv("NEUTRAL_STEAL_MIN", "0")
+    alone = _run(iface, prob, cs, 2, steps)
+    _same(want, alone)
+    assert sum(s.steals for s in alone[3]) == 0
+
+
 def test_tile_edge_follows_the_particle_density(iface, make_problem, cs):
     for deck, nx, n, want in (("csp", 100, 100000, 16), ("csp", 200, 100000, 32),
                               ("csp", 400, 100000, 64), ("stream", 1000, 20000, 128)):
