@@ -917,6 +917,17 @@ void history_regroup_kernel(SolveArgs a) {
              (double)(first - t0) * 1e-5, (double)g_wave_times[2] / (double)nwaves * 1e-5,
              (double)(last - t0) * 1e-5, (double)g_wave_times[5] / (double)nwaves, g_wave_times[6],
              (double)g_wave_times[7] * 1e-4, g_wave_times[8]);
+      {
+        /* (how many waves entered themselves in each CU's list: 16 everywhere in a full launch) */
+        unsigned lists = 0, full = 0, most = 0;
+        for (int i = 0; i < kCuSlots; ++i) {
+          const unsigned n_i = g_cu_count[i];
+          lists += n_i ? 1u : 0u;
+          full += (n_i == 16u) ? 1u : 0u;
+          most = (n_i > most) ? n_i : most;
+        }
+        printf("  CU lists: %u in use, %u of them with 16 waves, longest %u\n", lists, full, most);
+      }
       g_wave_times[0] = ~0ull; g_wave_times[1] = 0; g_wave_times[2] = 0; g_wave_times[3] = 0;
       g_wave_times[4] = ~0ull; g_wave_times[5] = 0; g_wave_times[6] = 0; g_wave_times[7] = 0;
       g_wave_times[8] = 0;
@@ -1349,9 +1360,13 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
           (void)hipGetSymbolAddress(&cu_count, HIP_SYMBOL(g_cu_count));
           (void)hipGetSymbolAddress(&cu_members, HIP_SYMBOL(g_cu_members));
         }
-        if (cu_count && cu_members) {
-          (void)hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream);
-          (void)hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream);
+        if (cu_count && cu_members &&
+            hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream) == hipSuccess &&
+            hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream) ==
+                hipSuccess) {
+          /* (lists empty, every entry invalid) */
+        } else {
+          k.steal_min = 0; /* no lists, no stealing: a stale list could name a wave of another CU */
         }
       }
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, k);
