@@ -349,6 +349,11 @@ constexpr int kCuWavesMax = 16;
 constexpr int kStealMin = NEUTRAL_STEAL_MIN; /* waiting histories a ring must hold to be taken from
                                                (SolveArgs::steal_min; 0: no stealing) */
 __device__ unsigned long long g_ring_ctl[kRingCtlSlots];
+/* waves that are reading entries out of a ring they have just taken from: a wave that re-uses
+ * its own (empty) ring for what IT takes from somebody waits until this is zero.  (A reader
+ * waits for nobody, so the wait ends; in practice the ring has been empty for milliseconds
+ * before its owner turns thief, and a copy takes microseconds.) */
+__device__ unsigned g_ring_readers[kRingCtlSlots];
 __device__ unsigned g_cu_count[kCuSlots];
 __device__ unsigned g_cu_members[kCuSlots * kCuWavesMax];
 
@@ -546,6 +551,8 @@ void history_regroup_kernel(SolveArgs a) {
   if (pooled && (threadIdx.x & 63) == 0) {
     g_ring_ctl[gw] = (unsigned long long)(unsigned)share; /* head 0 */
     if (a.steal_min > 0 && share > 0) {
+      /* (the ring's word is in memory before the wave shows up in its CU's list) */
+      __threadfence_block();
       const unsigned slot = atomicAdd(&g_cu_count[my_cu], 1u);
       if (slot < (unsigned)kCuWavesMax) {
         g_cu_members[my_cu * kCuWavesMax + slot] = (unsigned)gw;
@@ -601,10 +608,18 @@ void history_regroup_kernel(SolveArgs a) {
       if (lane == 0) {
         const unsigned long long seen = ((unsigned long long)v_head << 32) | best;
         const unsigned long long next = ((unsigned long long)new_head << 32) | (best - take);
+        atomicAdd(&g_ring_readers[v], 1u);
         won = (atomicCAS(&g_ring_ctl[v], seen, next) == seen) ? 1u : 0u;
+        if (!won) {
+          atomicSub(&g_ring_readers[v], 1u);
+        }
       }
       if (!wave_uniform(won)) {
         continue; /* (its owner or another CU-mate was quicker: look again) */
+      }
+      /* (nobody is still reading what was taken from THIS wave's ring earlier) */
+      while (__hip_atomic_load(&g_ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __builtin_amdgcn_s_sleep(2);
       }
       /* the entries [v_head, v_head + take) of v's ring are this wave's now */
       for (unsigned i = (unsigned)lane; i < take; i += 64u) {
@@ -616,6 +631,7 @@ void history_regroup_kernel(SolveArgs a) {
       }
       __threadfence_block();
       if (lane == 0) {
+        atomicSub(&g_ring_readers[v], 1u); /* (the loads above have returned: their values were stored) */
         atomicExch(&g_ring_ctl[gw], (unsigned long long)take); /* head 0, `take` waiting */
       }
       ring_tail = ((int)take >= share) ? (int)take - share : (int)take;
@@ -1356,14 +1372,17 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
         /* the CU lists of the collision stage's waves start empty (g_cu_count / g_cu_members) */
         static void* cu_count = nullptr;
         static void* cu_members = nullptr;
+        static void* ring_readers = nullptr;
         if (!cu_count) {
           (void)hipGetSymbolAddress(&cu_count, HIP_SYMBOL(g_cu_count));
           (void)hipGetSymbolAddress(&cu_members, HIP_SYMBOL(g_cu_members));
+          (void)hipGetSymbolAddress(&ring_readers, HIP_SYMBOL(g_ring_readers));
         }
-        if (cu_count && cu_members &&
+        if (cu_count && cu_members && ring_readers &&
             hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream) == hipSuccess &&
             hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream) ==
-                hipSuccess) {
+                hipSuccess &&
+            hipMemsetAsync(ring_readers, 0, sizeof(unsigned) * kRingCtlSlots, stream) == hipSuccess) {
           /* (lists empty, every entry invalid) */
         } else {
           k.steal_min = 0; /* no lists, no stealing: a stale list could name a wave of another CU */
