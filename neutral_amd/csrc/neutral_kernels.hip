@@ -344,7 +344,7 @@ constexpr int kRingCtlSlots = 8192;  /* waves of a launch (4 096 on an MI355X) *
 constexpr int kCuSlots = 4096;       /* (xcc 4 bits, se 3, sh 1, cu 4) */
 constexpr int kCuWavesMax = 16;
 #ifndef NEUTRAL_STEAL_MIN
-#define NEUTRAL_STEAL_MIN 128
+#define NEUTRAL_STEAL_MIN 96
 #endif
 constexpr int kStealMin = NEUTRAL_STEAL_MIN; /* waiting histories a ring must hold to be taken from
                                                (SolveArgs::steal_min; 0: no stealing) */
@@ -600,7 +600,10 @@ void history_regroup_kernel(SolveArgs a) {
       const int v = (int)__shfl(victim, src, 64);
       const unsigned v_head = (unsigned)__shfl((unsigned)(ctl >> 32), src, 64);
       const int v_share = (nwork - v + nwaves - 1) / nwaves;
+      /* half of it -- but a wave's worth where there is one: what a thief takes it runs in
+       * passes of its own, and a half-empty pass costs the SIMD what a full one costs */
       unsigned take = best / 2u;
+      take = (take < 64u) ? ((best < 64u) ? best : 64u) : take;
       take = (take > (unsigned)share) ? (unsigned)share : take;
       unsigned new_head = v_head + take;
       new_head = (new_head >= (unsigned)v_share) ? new_head - (unsigned)v_share : new_head;
