@@ -424,6 +424,7 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
 #if defined(NEUTRAL_EXP_WAVE_TIMES)
 __device__ unsigned long long g_wave_times[10] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_cu_last_exit[4096];
 #endif
 
 template <bool kSameTables, bool kQueue, bool kFlux, bool kChecked>
@@ -921,6 +922,7 @@ void history_regroup_kernel(SolveArgs a) {
     }
     atomicMin(&g_wave_times[0], now);
     atomicMax(&g_wave_times[1], now);
+    atomicMax(&g_cu_last_exit[cu_key()], now);
     atomicAdd(&g_wave_times[2], now - exp_t0);
     atomicMin(&g_wave_times[4], exp_t0);
     atomicAdd(&g_wave_times[5], (unsigned long long)w_collide_passes);
@@ -946,6 +948,23 @@ void history_regroup_kernel(SolveArgs a) {
           most = (n_i > most) ? n_i : most;
         }
         printf("  CU lists: %u in use, %u of them with 16 waves, longest %u\n", lists, full, most);
+        unsigned long long cu_first = ~0ull, cu_last = 0, cu_sum = 0, ncu = 0;
+        unsigned long long xcd_last[16] = {0};
+        for (int i = 0; i < 4096; ++i) {
+          const unsigned long long e = g_cu_last_exit[i];
+          if (e) {
+            cu_first = (e < cu_first) ? e : cu_first;
+            cu_last = (e > cu_last) ? e : cu_last;
+            cu_sum += e - t0;
+            ncu++;
+            xcd_last[i >> 8] = (e > xcd_last[i >> 8]) ? e : xcd_last[i >> 8];
+          }
+          g_cu_last_exit[i] = 0;
+        }
+        printf("  a CU's last wave out: earliest CU %.3f ms, mean %.3f, latest %.3f; XCDs' last:", (double)(cu_first - t0) * 1e-5,
+               (double)cu_sum / (double)(ncu ? ncu : 1) * 1e-5, (double)(cu_last - t0) * 1e-5);
+        for (int x = 0; x < 8; ++x) printf(" %.2f", xcd_last[x] ? (double)(xcd_last[x] - t0) * 1e-5 : 0.0);
+        printf("\n");
       }
       g_wave_times[0] = ~0ull; g_wave_times[1] = 0; g_wave_times[2] = 0; g_wave_times[3] = 0;
       g_wave_times[4] = ~0ull; g_wave_times[5] = 0; g_wave_times[6] = 0; g_wave_times[7] = 0;
