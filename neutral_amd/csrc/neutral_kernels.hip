@@ -356,6 +356,22 @@ __device__ unsigned long long g_ring_ctl[kRingCtlSlots];
 __device__ unsigned g_ring_readers[kRingCtlSlots];
 __device__ unsigned g_cu_count[kCuSlots];
 __device__ unsigned g_cu_members[kCuSlots * kCuWavesMax];
+/* ... and the same per XCD (the CUs of an XCD share its L2): where a wave looks when its own
+ * CU has nothing left to take.  What it takes there was written on another CU: it is in the
+ * L2 the two share (stores are write-through and complete before their ring says that they
+ * wait), and the thief drops what its own L1 may still hold of those lines (an acquire at
+ * agent scope: buffer_inv) before it reads any of it.  Built, correct (the steal test passes
+ * with it) and SLOWER: csp collision stage 332 against 326 ms per 10 steps, 178 against 172 at
+ * 5e7 particles (profiles/r03/experiments/collision_wave_exit_times.log) -- histories that
+ * change CU arrive cold, and the CUs of an XCD end within 2 % of each other anyway.  Off
+ * (NEUTRAL_STEAL_XCD=1: the experiment). */
+constexpr int kXcdSlots = 16;
+constexpr int kXcdWavesMax = 1024;
+__device__ unsigned g_xcd_count[kXcdSlots];
+__device__ unsigned g_xcd_members[kXcdSlots * kXcdWavesMax];
+#ifndef NEUTRAL_STEAL_XCD
+#define NEUTRAL_STEAL_XCD 0
+#endif
 
 __device__ __forceinline__ unsigned cu_key() {
   /* HW_ID (s_getreg id 4): cu [11:8], sh [12], se [15:13]; XCC_ID (id 20): [3:0] */
@@ -558,6 +574,13 @@ void history_regroup_kernel(SolveArgs a) {
       if (slot < (unsigned)kCuWavesMax) {
         g_cu_members[my_cu * kCuWavesMax + slot] = (unsigned)gw;
       }
+      if (NEUTRAL_STEAL_XCD) {
+        const unsigned xcd = my_cu >> 8;
+        const unsigned xslot = atomicAdd(&g_xcd_count[xcd], 1u);
+        if (xslot < (unsigned)kXcdWavesMax) {
+          g_xcd_members[xcd * kXcdWavesMax + xslot] = (unsigned)gw;
+        }
+      }
     }
   }
   /* a wave whose ring is empty and whose lanes are idle: half of what waits in the fullest
@@ -571,35 +594,57 @@ void history_regroup_kernel(SolveArgs a) {
       return false;
     }
     const int lane = (int)(threadIdx.x & 63);
+    /* the fullest ring among `count` waves listed at `members`: its wave, its control word */
+    auto fullest = [&](const unsigned* members, unsigned count, int& v_out, unsigned& head_out) -> unsigned {
+      unsigned best = 0, best_victim = 0, best_head = 0;
+      for (unsigned base = 0; base < count; base += 64u) {
+        unsigned victim = ~0u;
+        unsigned long long ctl = 0;
+        if (base + (unsigned)lane < count) {
+          victim = __hip_atomic_load(&members[base + (unsigned)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          /* (the launch starts with every entry invalid; a wave that has only counted itself
+           * in so far is not looked at) */
+          if (victim < (unsigned)nwaves && (int)victim != gw) {
+            ctl = ring_ctl_load((int)victim);
+          }
+        }
+        const unsigned waiting = (unsigned)ctl;
+        unsigned most = waiting;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned other = __shfl_xor(most, off, 64);
+          most = (other > most) ? other : most;
+        }
+        most = wave_uniform(most);
+        if (most > best) {
+          const int src = __builtin_ctzll(__ballot(waiting == most));
+          best = most;
+          best_victim = (unsigned)__shfl(victim, src, 64);
+          best_head = (unsigned)__shfl((unsigned)(ctl >> 32), src, 64);
+        }
+      }
+      v_out = (int)best_victim;
+      head_out = best_head;
+      return best;
+    };
     for (int attempt = 0; attempt < 4; ++attempt) {
       unsigned mates = __hip_atomic_load(&g_cu_count[my_cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       mates = (mates > (unsigned)kCuWavesMax) ? (unsigned)kCuWavesMax : mates;
-      unsigned victim = 0;
-      unsigned long long ctl = 0;
-      if ((unsigned)lane < mates) {
-        victim = __hip_atomic_load(&g_cu_members[my_cu * kCuWavesMax + lane], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        /* (the launch starts with every entry invalid; a mate that has only counted itself
-         * in so far is not looked at) */
-        if (victim < (unsigned)nwaves && (int)victim != gw) {
-          ctl = ring_ctl_load((int)victim);
-        }
+      int v = 0;
+      unsigned v_head = 0;
+      unsigned best = fullest(&g_cu_members[my_cu * kCuWavesMax], mates, v, v_head);
+      bool other_cu = false;
+      if ((best < steal_min || best < 2u) && NEUTRAL_STEAL_XCD) {
+        /* nothing on this CU: the other CUs of the XCD */
+        const unsigned xcd = my_cu >> 8;
+        unsigned n = __hip_atomic_load(&g_xcd_count[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = (n > (unsigned)kXcdWavesMax) ? (unsigned)kXcdWavesMax : n;
+        best = fullest(&g_xcd_members[xcd * kXcdWavesMax], n, v, v_head);
+        other_cu = true;
       }
-      unsigned waiting = (unsigned)ctl;
-      unsigned best = waiting;
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        const unsigned other = __shfl_xor(best, off, 64);
-        best = (other > best) ? other : best;
-      }
-      best = wave_uniform(best); /* (the maximum over lanes 0..15, in lane 0) */
       if (best < steal_min || best < 2u) {
         return false;
       }
-      const unsigned long long m_best = __ballot((unsigned)lane < mates && waiting == best);
-      const int src = __builtin_ctzll(m_best);
-      const int v = (int)__shfl(victim, src, 64);
-      const unsigned v_head = (unsigned)__shfl((unsigned)(ctl >> 32), src, 64);
       const int v_share = (nwork - v + nwaves - 1) / nwaves;
       /* half of it -- but a wave's worth where there is one: what a thief takes it runs in
        * passes of its own, and a half-empty pass costs the SIMD what a full one costs */
@@ -619,7 +664,10 @@ void history_regroup_kernel(SolveArgs a) {
         }
       }
       if (!wave_uniform(won)) {
-        continue; /* (its owner or another CU-mate was quicker: look again) */
+        continue; /* (its owner or another thief was quicker: look again) */
+      }
+      if (other_cu) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* (nothing stale of it in this CU's L1) */
       }
       /* (nobody is still reading what was taken from THIS wave's ring earlier) */
       while (__hip_atomic_load(&g_ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -1395,12 +1443,19 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
         static void* cu_count = nullptr;
         static void* cu_members = nullptr;
         static void* ring_readers = nullptr;
+        static void* xcd_count = nullptr;
+        static void* xcd_members = nullptr;
         if (!cu_count) {
           (void)hipGetSymbolAddress(&cu_count, HIP_SYMBOL(g_cu_count));
           (void)hipGetSymbolAddress(&cu_members, HIP_SYMBOL(g_cu_members));
           (void)hipGetSymbolAddress(&ring_readers, HIP_SYMBOL(g_ring_readers));
+          (void)hipGetSymbolAddress(&xcd_count, HIP_SYMBOL(g_xcd_count));
+          (void)hipGetSymbolAddress(&xcd_members, HIP_SYMBOL(g_xcd_members));
         }
-        if (cu_count && cu_members && ring_readers &&
+        if (cu_count && cu_members && ring_readers && xcd_count && xcd_members &&
+            hipMemsetAsync(xcd_count, 0, sizeof(unsigned) * kXcdSlots, stream) == hipSuccess &&
+            hipMemsetAsync(xcd_members, 0xFF, sizeof(unsigned) * kXcdSlots * kXcdWavesMax, stream) ==
+                hipSuccess &&
             hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream) == hipSuccess &&
             hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream) ==
                 hipSuccess &&
