@@ -1422,15 +1422,6 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       if (a.max_blocks > 0 && grid > a.max_blocks) {
         grid = a.max_blocks;
       }
-      {
-        /* (tests: a collision stage of a few workgroups gives a test deck's waves shares as
-         * long as a full-size run's) */
-        const char* limit = getenv("NEUTRAL_COLLISION_BLOCKS");
-        if (a.queue && limit && atoi(limit) > 0 && grid > atoi(limit)) {
-          grid = atoi(limit);
-          k.occupancy_rows = 0;
-        }
-      }
       k.steal_min = kStealMin;
       {
         const char* force = getenv("NEUTRAL_STEAL_MIN"); /* (tests: small rings taken from too) */
