@@ -80,6 +80,26 @@ __global__ __launch_bounds__(kBlock) void gather_records(const Rec* rec, const u
   if (k < n) out[k] = rec[slot_of_id[k]];
 }
 
+// ... in batches whose id-ordered staging buffer stays in the memory-side cache: a gather
+// launch (random reads from HBM, stores absorbed by the cache) and a transpose launch (reads
+// from the cache, the eleven arrays streamed out) per batch -- reads and writes of HBM
+// separated in time
+template <int kBlock>
+__global__ __launch_bounds__(kBlock) void gather_range(const Rec* rec, const unsigned* slot_of_id, Rec* stage,
+                                                       int first, int count) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < count) stage[k] = rec[slot_of_id[first + k]];
+}
+template <int kBlock>
+__global__ __launch_bounds__(kBlock) void transpose_range(const Rec* stage, View p, int first, int count) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= count) return;
+  const Rec r = stage[j];
+  const int k = first + j;
+  p.x[k] = r.x; p.y[k] = r.y; p.ox[k] = r.ox; p.oy[k] = r.oy; p.e[k] = r.e; p.w[k] = r.w;
+  p.dt[k] = r.dt; p.mfp[k] = r.mfp; p.cx[k] = r.cx; p.cy[k] = r.cy; p.dead[k] = r.dead;
+}
+
 // kPer ids per thread, all slot loads first, then all record loads, then the stores
 template <int kBlock, int kPer>
 __global__ __launch_bounds__(kBlock) void by_id_ilp(const Rec* rec, const unsigned* slot_of_id, View p, int n) {
@@ -222,6 +242,20 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&tmp, sizeof(Rec) * (size_t)n));
     report("gather into id order only (80-B stores)", timed([&] { gather_records<256><<<(n + 255) / 256, 256>>>(rec, d_slot, tmp, n); }, reps));
     CHECK(hipFree(tmp));
+  }
+  for (int batch : {400000, 1600000, 3200000, 12800000}) {
+    Rec* stage;
+    CHECK(hipMalloc((void**)&stage, sizeof(Rec) * (size_t)batch));
+    char name[96];
+    snprintf(name, sizeof(name), "two launches per batch of %d ids (%.0f MB staged)", batch, batch * 80.0 / 1e6);
+    report(name, timed([&] {
+      for (int first = 0; first < n; first += batch) {
+        const int count = (n - first < batch) ? n - first : batch;
+        gather_range<256><<<(count + 255) / 256, 256>>>(rec, d_slot, stage, first, count);
+        transpose_range<256><<<(count + 255) / 256, 256>>>(stage, p, first, count);
+      }
+    }, reps));
+    CHECK(hipFree(stage));
   }
   report("by slot (coalesced reads, eleven scattered stores)", timed([&] { by_slot<256><<<(n + 255) / 256, 256>>>(rec, p, n); }, reps));
   return 0;
