@@ -292,7 +292,7 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
  * would execute unsliced: the record, the RNG counter and the pending
  * deposition are all that survives a loop head (see resume()). */
 #ifndef NEUTRAL_SLICE_PASSES
-#define NEUTRAL_SLICE_PASSES 128 /* (64 until the rings were evened out by stealing: -1.6 % on csp 1e8 now) */
+#define NEUTRAL_SLICE_PASSES 64 /* (128 or 256 measure the same with the rings evened out by stealing) */
 #endif
 constexpr int kSlicePasses = NEUTRAL_SLICE_PASSES;
 /* Measured (profiles/r01g/ablate_shares.log, ablate_slicewindow.log):
