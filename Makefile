@@ -9,8 +9,11 @@ SHELL := /bin/bash
 test-cpu: all
 	set -o pipefail; NEUTRAL_FULL_KATS=1 python -m pytest tests -x -q -rA -m "not gpu" 2>&1 | tee oracle/pins/_latest.log
 
-pin-kats: test-cpu
-	{ echo "# make test-cpu at $$(git rev-parse --short HEAD)$$(git diff --quiet || echo +dirty), $$(date -u +%Y-%m-%dT%H:%MZ)"; \
+# (the tracked record is made from a clean tree only: what it names is what was tested)
+pin-kats:
+	@git diff --quiet && git diff --cached --quiet || { echo "pin-kats: the tree has uncommitted changes: commit first"; exit 1; }
+	$(MAKE) test-cpu
+	{ echo "# make test-cpu at $$(git rev-parse --short HEAD), $$(date -u +%Y-%m-%dT%H:%MZ)"; \
 	  echo "# oracle/neutral_oracle.c sha256 $$(sha256sum oracle/neutral_oracle.c | cut -c1-16)"; \
 	  grep -E "PASSED|FAILED|SKIPPED|passed|failed|tally=" oracle/pins/_latest.log; } > oracle/pins/full_kats.log
 

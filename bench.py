@@ -128,6 +128,9 @@ PRIMARY_EVENT = {"stream_kernel": "facets", "history_regroup_kernel": "collision
                  "history_kernel": "collisions"}
 
 
+FLUX = False  # --flux: the committed PMC coefficients are those of the kernels without it
+
+
 def profile_entry(deck, nx, variant, kernel):
     """The committed rocprofv3 PMC figures of `kernel` for this deck and mesh
     (profiles/pmc_per_event.json, made by tools/pmc_events.py from separate --pmc
@@ -140,7 +143,8 @@ def profile_entry(deck, nx, variant, kernel):
     except OSError:
         return None
     for e in table.get("entries", []):
-        if (e["deck"], e["nx"], e["variant"], e["kernel"]) == (deck, nx, variant, kernel):
+        if (e["deck"], e["nx"], e["variant"], e["kernel"], bool(e.get("flux", False))) == \
+                (deck, nx, variant, kernel, FLUX):
             return e
     return None
 
@@ -151,12 +155,24 @@ HOT_LOOP = {"stream_kernel": "facet", "history_regroup_kernel": "collide",
 
 def isa_mix(kernel):
     """Mean issue cycles per vector instruction of the kernel's hot loop and how much of
-    that is priced by measured opcodes (profiles/isa_mix.json, tools/isa_histogram.py)."""
+    that is priced by measured opcodes (profiles/isa_mix.json, tools/isa_histogram.py), and
+    whether the listing it was made from is that of the device sources in this tree."""
     try:
         with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
-            return json.load(f).get(HOT_LOOP.get(kernel, ""))
+            table = json.load(f)
     except OSError:
         return None
+    mix = table.get(HOT_LOOP.get(kernel, ""))
+    if mix is None:
+        return None
+    mix = dict(mix)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import isa_histogram
+        mix["listing_matches_sources"] = table.get("source_sha16") == isa_histogram.source_sha16()
+    except Exception:
+        mix["listing_matches_sources"] = None
+    return mix
 
 
 def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None):
@@ -185,6 +201,11 @@ def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None)
            "share_of_loop_cycles_priced_by_measured_opcodes": mix["cycles_priced_by_measurement"],
            "valu_insts_per_event": c["SQ_INSTS_VALU"], "event": PRIMARY_EVENT[kernel],
            "events_per_launch": n / launches,
+           "frac_kind": "modelled: a measured instruction count (PMC, per event x this run's events) "
+                        "priced with the STATIC mix of the hot loop; prologue, refill, hand-back and "
+                        "rare paths are priced as if they had the loop's mix.  frac_from_pass_count "
+                        "(collision stage) is the same from the kernel's own dynamic pass count",
+           "isa_listing_matches_sources": mix.get("listing_matches_sources"),
            "pricing": "instruction count: rocprofv3 --pmc SQ_INSTS_VALU per event x this run's "
                       "events; cycles per instruction: the hot loop's opcodes (tools/isa_histogram.py "
                       "on the shipped ISA) x the issue cost measured per opcode "
@@ -296,6 +317,12 @@ def parse_args():
     ap.add_argument("--record-one-rank", action="store_true",
                     help="N = 1: write this run's event totals and global tally to "
                          "profiles/one_rank_tally.json (what N > 1 lines are checked against)")
+    ap.add_argument("--flux", action="store_true",
+                    help="keep the scalar-flux tally next to the energy deposition (SURVEY 8f-3: two "
+                         "88-cell LDS windows instead of one of 128 cells)")
+    ap.add_argument("--decompose", default=None, metavar="PXxPY",
+                    help="N > 1: spatial domain decomposition (SURVEY 8f-4) -- every rank owns a block "
+                         "of the mesh and the particles inside it; histories migrate between ranks")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU work of the cpu_baseline sample")
     return ap.parse_args()
@@ -353,6 +380,14 @@ def main():
     # ROCr reads this at start-up: multi-process GPU work on this pool needs dmabuf IPC
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
+    global FLUX
+    FLUX = bool(args.flux)
+    domain = None
+    if args.decompose:
+        px, _, py = args.decompose.lower().partition("x")
+        domain = (int(px), int(py))
+        if domain[0] * domain[1] != args.gpus:
+            raise SystemExit(f"--decompose {args.decompose} needs --gpus {domain[0] * domain[1]}")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not under a launcher: start one (child process; nothing here has touched the GPU)
@@ -429,7 +464,8 @@ def main():
                                 ny=nx, nparticles=ntotal, iterations=max(K, 1))
         prob = host.setup_problem(path, decks.ARCH_WIDTH, decks.ARCH_HEIGHT)
         # shard=None: with several ranks inject_particles cuts this rank's share itself
-        sim = iface.Simulation(prob, keys, values, device=local_rank, variant=args.variant)
+        sim = iface.Simulation(prob, keys, values, device=local_rank, variant=args.variant,
+                               scalar_flux=args.flux, domain=domain)
 
         def timed_region(lazy):
             """W warm-up steps, re-injection, K timed steps; returns (results, seconds,
@@ -440,6 +476,8 @@ def main():
                 sim.step(tt)
             sim.inject()
             sim.tally.zero_()
+            if sim.flux is not None:
+                sim.flux.zero_()
             fence()
             t0 = time.perf_counter()
             results = [sim.step(tt) for tt in range(1, K + 1)]
@@ -461,8 +499,69 @@ def main():
         # ---- the headline: the library as an unmodified main.c drives it ----
         results, elapsed, tot, _ = timed_region(lazy=False)
         stats = iface.last_step()
+        # ---- what a first multi-GPU record needs to be read: every rank's own view ----
+        ranks_view = None
+        if world > 1:
+            import ctypes as C
+            mine = [float(transport),
+                    sum(r.stats.kernel_ms + r.stats.export_ms for r in results) / K,
+                    sum(r.stats.stream_ms for r in results) / K,
+                    sum(r.stats.collide_ms for r in results) / K,
+                    sum(r.stats.exchange_ms for r in results) / K,
+                    float(results[-1].stats.local_nprocessed),
+                    float(sim.n)]
+            t = torch.zeros(world * len(mine), dtype=torch.float64, device=sim.device)
+            t[rank * len(mine):(rank + 1) * len(mine)] = torch.tensor(mine, dtype=torch.float64)
+            torch.cuda.synchronize()
+            lib.neutral_hip_comm_allreduce_f64(C.c_void_p(t.data_ptr()), t.numel(),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            rows = t.cpu().reshape(world, len(mine)).tolist()
+
+            def spread(col):
+                v = [row[col] for row in rows]
+                return {"min": min(v), "max": max(v), "per_rank": v}
+            names = {iface.COMM_NONE: "none", iface.COMM_RCCL: "rccl", iface.COMM_HOST: "host"}
+            ranks_view = {
+                "rccl_version": int(lib.neutral_hip_comm_rccl_version()),
+                "transport_asked": args.comm,
+                "transport_per_rank": [names.get(int(row[0]), "?") for row in rows],
+                "device_ms_per_step": spread(1),   # kernels + write-back, HIP events, this rank
+                "stream_ms_per_step": spread(2),
+                "collide_ms_per_step": spread(3),
+                "exchange_ms_per_step": spread(4),  # on the library's own stream
+                "particles_alive_last_step": spread(5),
+                "particles_in_shard": spread(6),
+            }
+            if domain is not None:
+                mine2 = [sum(r.stats.exchange_rounds for r in results) / K,
+                         sum(r.stats.emigrants for r in results) / K,
+                         sum(r.stats.stream_passes for r in results) / K]
+                t2 = torch.zeros(world * 3, dtype=torch.float64, device=sim.device)
+                t2[rank * 3:(rank + 1) * 3] = torch.tensor(mine2, dtype=torch.float64)
+                torch.cuda.synchronize()
+                lib.neutral_hip_comm_allreduce_f64(C.c_void_p(t2.data_ptr()), t2.numel(),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                rows2 = t2.cpu().reshape(world, 3).tolist()
+                ranks_view["decomposition"] = {
+                    "grid": args.decompose,
+                    "exchange_rounds_per_step": max(r2[0] for r2 in rows2),
+                    "emigrants_per_step_per_rank": [r2[1] for r2 in rows2],
+                    "emigrants_per_round": (sum(r2[1] for r2 in rows2) /
+                                            max(1.0, max(r2[0] for r2 in rows2))),
+                    "stream_passes_per_step_per_rank": [r2[2] for r2 in rows2]}
         particle_steps = tot["facets"] + tot["collisions"] + tot["census"]
         global_tally = float(sim.tally.sum().item())
+        if domain is not None:
+            # (every rank tallies the cells of its block: the global tally is the sum of the blocks')
+            import ctypes as C
+            g1 = torch.tensor([global_tally], dtype=torch.float64, device=sim.device)
+            torch.cuda.synchronize()
+            lib.neutral_hip_comm_allreduce_f64(C.c_void_p(g1.data_ptr()), 1,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            global_tally = float(g1.item())
         lazy = None
         if not args.no_lazy_leg:
             l_results, l_elapsed, l_tot, l_wb = timed_region(lazy=True)
@@ -536,9 +635,13 @@ def main():
                                         "particles)" if args.workload == "csp" else
                                         f" (--workload {args.workload})"),
                            "deck": deck, "nx": nx, "ny": nx, "nparticles": ntotal,
-                           "timesteps": K, "parallelism": f"particle-shard x{world}",
+                           "timesteps": K,
+                           "parallelism": (f"mesh blocks {args.decompose}" if domain is not None
+                                           else f"particle-shard x{world}"),
                            "kernel_variant": variant,
                            "particle_arrays": "current after every step (default ABI)",
+                           "scalar_flux_tally": bool(args.flux),
+                           "decomposition": args.decompose,
                            "tally_exchange": {iface.COMM_NONE: "none (one rank)",
                                               iface.COMM_RCCL: "RCCL all-reduce per step",
                                               iface.COMM_HOST: "staged through the host (TCP)"}
@@ -549,6 +652,10 @@ def main():
                 "global_tally": global_tally,
                 "host_waits_per_step": int(stats.host_syncs),
                 "stream_passes_per_step": int(stats.stream_passes),
+                "stream_queue": {"hops_per_step": sum(r.stats.stream_hops for r in results) / K,
+                                 "batches_per_step": sum(r.stats.stream_batches for r in results) / K,
+                                 "overflows_per_step": sum(r.stats.stream_overflows for r in results) / K,
+                                 "idle_polls_per_step": sum(r.stats.stream_idle_polls for r in results) / K},
                 "tile_cells": int(stats.tile_cells),
                 "lazy_export": lazy,
                 "roofline": roofline,
@@ -556,6 +663,10 @@ def main():
             }
             out["exchange"] = {"ranks_summed_over": int(stats.exchange_ranks),
                                "host_collectives_per_step": int(stats.host_collectives)}
+            if ranks_view is not None:
+                out["ranks"] = ranks_view
+            if args.flux:
+                out["scalar_flux_sum"] = float(sim.flux.sum().item())
             if world > 1:
                 rec = one_rank_record(deck, nx, ntotal, K)
                 if rec is None:
@@ -613,6 +724,15 @@ def main():
     if world > 1:
         lib.neutral_hip_comm_barrier()
         lib.neutral_hip_comm_stop()
+        # RCCL was asked for and the ranks staged their exchange through the host instead: the
+        # line above is a measurement of THAT, and must not pass for the RCCL figure
+        if args.comm == "rccl" and transport != iface.COMM_RCCL:
+            if rank == 0:
+                print(f"bench.py: RCCL was asked for (--comm rccl) but the ranks fell back to the "
+                      f"host route (transport {transport}): see the library's message above; "
+                      f"the JSON line says so in ranks.transport_per_rank", file=sys.stderr,
+                      flush=True)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -195,6 +195,28 @@ typedef struct {
   int exchange_ranks;    /* ranks the last tally exchange summed over (1: no exchange) */
   uint64_t steals;       /* tiled variant: times a wave of the collision stage that had emptied
                             its ring took half of what waited in the ring of a wave of its CU */
+  uint64_t steals_refused; /* ... waves that would have taken but did not, because the key
+                            that tells them who shares their CU (read from the hardware)
+                            collected more waves than a CU holds in this launch: the launch
+                            then steals nothing (0 on an MI355X) */
+  uint64_t stream_hops;  /* tiled variant: histories that left the tally window of the tile they
+                            were streaming under with far to go and were handed, INSIDE the stream
+                            kernel, to the queue of the tile they had reached (no further pass) */
+  uint64_t stream_overflows; /* ... and those that found that tile's queue full and waited for
+                            another pass of the stream stage instead (0 unless a tile receives
+                            more than its queue holds in one launch) */
+  uint64_t stream_batches; /* ... claims of a workgroup on a tile's queue (stream_hops / this =
+                            histories a workgroup streams under one window placement) */
+  uint64_t stream_idle_polls; /* ... times a workgroup looked for work and found none while
+                            histories were still in flight elsewhere */
+  uint64_t local_nprocessed; /* several ranks: live particles THIS rank advanced (nprocessed is
+                            the sum over the ranks then) */
+  double exchange_ms;    /* several ranks: HIP-event time of the step's tally exchange (pack, the
+                            two all-reduces, the add into the caller's mesh) on the library's own
+                            stream, beside the write-back; 0 with one rank */
+  int exchange_rounds;   /* decomposed mesh: rounds of the particle exchange between the ranks'
+                            blocks the step took (each: count, pack, exchange, append, more passes) */
+  uint64_t emigrants;    /* decomposed mesh: histories THIS rank sent to other ranks' blocks */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */
@@ -319,6 +341,8 @@ void neutral_hip_comm_stop(void);
 int neutral_hip_comm_rank(void);
 int neutral_hip_comm_nranks(void);
 int neutral_hip_comm_transport(void);
+/* RCCL's version number as ncclGetVersion reports it (0: librccl is not loadable here) */
+int neutral_hip_comm_rccl_version(void);
 /* sharding by inject_particles when there are several ranks (default 1); 0 leaves the
  * id range to the caller (neutral_hip_set_pid_base + its own particle count) */
 void neutral_hip_set_auto_shard(int on);

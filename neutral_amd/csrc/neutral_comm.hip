@@ -365,6 +365,21 @@ int neutral_hip_comm_rank(void) { return neutral::comm_rank(); }
 int neutral_hip_comm_nranks(void) { return neutral::comm_nranks(); }
 int neutral_hip_comm_transport(void) { return c.transport; }
 
+/* RCCL's own version number (ncclGetVersion: e.g. 22203 for 2.22.3), 0 when librccl cannot be
+ * loaded here -- what a first multi-GPU record should say it ran on */
+int neutral_hip_comm_rccl_version(void) {
+  if (!c.rccl.handle && !load_rccl(c.rccl)) {
+    return 0;
+  }
+  typedef ncclResult_t (*GetVersion)(int*);
+  GetVersion get = (GetVersion)dlsym(c.rccl.handle, "ncclGetVersion");
+  int v = 0;
+  if (!get || get(&v) != 0) {
+    return 0;
+  }
+  return v;
+}
+
 void neutral_hip_comm_allreduce_f64(double* device_buf, size_t n, void* hip_stream) {
   neutral::comm_allreduce_sum(device_buf, n, true, (hipStream_t)hip_stream);
 }

@@ -325,7 +325,7 @@ __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, dou
 
 /* fma(r, z, c) as ONE three-operand instruction (c stays where it is) */
 __device__ __forceinline__ double horner_step(double r, double z, double c) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(NEUTRAL_NO_HORNER_ASM)
+#if defined(__HIP_DEVICE_COMPILE__)
   double out;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(r), "v"(z), "v"(c));
   return out;

@@ -106,12 +106,7 @@ struct GlobalTallyT {
                                              double energy_deposition) const {
     const int cellx = pcellx - a.x_off;
     const int celly = pcelly - a.y_off;
-#if defined(NEUTRAL_EXP_NO_TALLY)
-    /* timing experiment only: keep the value alive, drop the memory operation */
-    if (energy_deposition == 1.2345e300) a.tally[celly * a.nx + cellx] = energy_deposition;
-#else
     unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), energy_deposition * a.inv_ntotal_particles);
-#endif
   }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
                                        double track_length) const {
@@ -156,10 +151,6 @@ struct WindowTallyT {
   }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
-#if defined(NEUTRAL_EXP_NO_TALLY)
-    if (energy_deposition == 1.2345e300) window[0] = energy_deposition; /* timing experiment only */
-    return;
-#endif
     add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
   }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
@@ -215,10 +206,6 @@ struct WindowCellTallyT {
   }
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
-#if defined(NEUTRAL_EXP_NO_TALLY)
-    if (energy_deposition == 1.2345e300) window[0] = energy_deposition; /* timing experiment only */
-    return;
-#endif
     add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
   }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
@@ -250,14 +237,6 @@ template <bool kSameTables, bool kChecked, typename IndexPtr>
 __device__ __forceinline__ void lookup_cs(const SolveArgs& a, const CsLookup<IndexPtr>& ix,
                                           double energy, double& micro_scatter,
                                           double& micro_absorb) {
-#if defined(NEUTRAL_EXP_NO_LOOKUP)
-  /* timing experiment only: no table access, a value of the right magnitude */
-  micro_scatter = 900.0 + energy * 1e-9;
-  if (kSameTables) {
-    micro_absorb = micro_scatter;
-    return;
-  }
-#endif
   const int is = bracket_of(a.scatter_keys, a.scatter_n, ix.scatter_index, a.scatter_index_n,
                             a.index_shift, a.scatter_index_base, energy);
   micro_scatter = cs_interpolate<kChecked>(a.scatter_keys, a.scatter_values, is, energy);
@@ -560,8 +539,11 @@ __device__ __forceinline__ bool outside_domain(const History& h, const SolveArgs
          ((unsigned)(h.celly - a.y_off) >= (unsigned)a.ny);
 }
 
-__device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
-                                             ParticleRec& r, int state) {
+typedef unsigned rec_quad __attribute__((ext_vector_type(4)));
+constexpr int kRecQuads = kParticleRecBytes / 16;
+
+/* the 80 bytes a record holds as five 16-byte quads (not the padding of an over-aligned one) */
+__device__ __forceinline__ void record_quads(const History& h, int state, rec_quad (&q)[kRecQuads]) {
   ParticleRec o;
   o.x = h.x;
   o.y = h.y;
@@ -575,15 +557,113 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
   o.celly = h.celly;
   o.id = h.id;
   o.dead = record_word(state, h.counter);
-  /* (the 80 bytes a record holds, as five 16-byte stores: not the padding of an
-   * over-aligned record) */
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  const v4u* src = (const v4u*)&o;
-  v4u* dst = (v4u*)&r;
+  __builtin_memcpy(q, &o, kParticleRecBytes); /* (registers to registers: no type punning) */
+}
+
+__device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
+                                             ParticleRec& r, int state) {
+  rec_quad q[kRecQuads];
+  record_quads(h, state, q);
+  rec_quad* dst = (rec_quad*)__builtin_assume_aligned(&r, 16);
 #pragma unroll
-  for (int k = 0; k < kParticleRecBytes / 16; ++k) {
-    dst[k] = src[k];
+  for (int k = 0; k < kRecQuads; ++k) {
+    dst[k] = q[k];
   }
+}
+
+/* ---- records that change hands INSIDE a launch --------------------------------------
+ * A record that another workgroup may pick up before the kernel ends (a migrant queued for
+ * another tile's window in the stream kernel, a history handed back to a ring of the
+ * collision stage that a CU-mate may take from) is stored WRITE-THROUGH (sc1: the bytes
+ * leave this XCD's L2 for the memory side) and the storing wave waits for its stores
+ * (drain_stores) BEFORE it publishes the record's number with an agent-scope atomic; whoever
+ * picks the number up loads the record with sc1 loads, which bypass its CU's L1 (never
+ * refreshed by other CUs' stores).  tools/micro/handoff_litmus.hip is this protocol on records
+ * that share 128-byte lines with records other workgroups are rewriting at the same time, across
+ * XCDs: 0 stale of 6.3e6 hops, where plain accesses see 1.6e6 (profiles/r04/experiments/). */
+__device__ __forceinline__ void store_record_through(const History& h, const SolveArgs& a,
+                                                     ParticleRec& r, int state) {
+  rec_quad q[kRecQuads];
+  record_quads(h, state, q);
+  static_assert(kRecQuads == 5, "five quads");
+  asm volatile(
+      "global_store_dwordx4 %0, %1, off sc1\n"
+      "global_store_dwordx4 %0, %2, off offset:16 sc1\n"
+      "global_store_dwordx4 %0, %3, off offset:32 sc1\n"
+      "global_store_dwordx4 %0, %4, off offset:48 sc1\n"
+      "global_store_dwordx4 %0, %5, off offset:64 sc1\n"
+      /* (a store of more than 8 bytes reads its data registers up to two wait states after it
+       * issues, and the compiler pads nothing around an asm statement: without this its next
+       * instruction may overwrite them first -- the stream kernel's did, with the -1 of an
+       * initialiser, in one record of eight; cdna_hip_programming.md 5.7 item 1) */
+      "s_nop 1"
+      :
+      : "v"(&r), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4])
+      : "memory");
+}
+
+/* every vector-memory operation of this wave has completed (gfx9: loads and stores share
+ * vmcnt): what it stored write-through is where others can see it */
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void load_record_through(History& h, const SolveArgs& a,
+                                                    const ParticleRec& r) {
+  rec_quad q[kRecQuads];
+  asm volatile(
+      "global_load_dwordx4 %0, %5, off sc1\n"
+      "global_load_dwordx4 %1, %5, off offset:16 sc1\n"
+      "global_load_dwordx4 %2, %5, off offset:32 sc1\n"
+      "global_load_dwordx4 %3, %5, off offset:48 sc1\n"
+      "global_load_dwordx4 %4, %5, off offset:64 sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4])
+      : "v"(&r)
+      : "memory");
+  ParticleRec o;
+  __builtin_memcpy(&o, q, kParticleRecBytes);
+  load_record(h, a, o);
+}
+
+/* ... together with the 16-byte side record that belongs to it (SuspendExtra): six loads, one wait */
+template <typename T>
+__device__ __forceinline__ void load_record_through(History& h, const SolveArgs& a,
+                                                    const ParticleRec& r, const T* side, T& side_out) {
+  static_assert(sizeof(T) == 16, "one quad");
+  rec_quad q[kRecQuads];
+  rec_quad s;
+  asm volatile(
+      "global_load_dwordx4 %0, %6, off sc1\n"
+      "global_load_dwordx4 %1, %6, off offset:16 sc1\n"
+      "global_load_dwordx4 %2, %6, off offset:32 sc1\n"
+      "global_load_dwordx4 %3, %6, off offset:48 sc1\n"
+      "global_load_dwordx4 %4, %6, off offset:64 sc1\n"
+      "global_load_dwordx4 %5, %7, off sc1\n"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(s)
+      : "v"(&r), "v"(side)
+      : "memory");
+  ParticleRec o;
+  __builtin_memcpy(&o, q, kParticleRecBytes);
+  load_record(h, a, o);
+  __builtin_memcpy(&side_out, &s, 16);
+}
+
+/* a 16-byte side record (SuspendExtra) the same way */
+template <typename T>
+__device__ __forceinline__ void store_through16(T* dst, const T& v) {
+  static_assert(sizeof(T) == 16, "one quad");
+  rec_quad q;
+  __builtin_memcpy(&q, &v, 16);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\ns_nop 1" : : "v"(dst), "v"(q) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ T load_through16(const T* src) {
+  static_assert(sizeof(T) == 16, "one quad");
+  rec_quad q;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\ns_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+  T v;
+  __builtin_memcpy(&v, &q, 16);
+  return v;
 }
 
 /* omp3/neutral.c:103-131 (initial == 1 always: :35-36) */
@@ -694,18 +774,9 @@ __device__ __forceinline__ bool next_is_collision(History& h, const CellEdges& e
   /* (x_lo_open = e.x_lo - OPEN_BOUND_CORRECTION, worked out when the cell was entered: a
    * collision changes the direction, not the cell) */
   double distance_to_facet;
-#if !defined(NEUTRAL_NO_LO_OPEN)
   calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv,
                            (h.omega_x >= 0.0) ? e.x_hi : x_lo_open,
                            (h.omega_y >= 0.0) ? e.y_hi : y_lo_open, distance_to_facet, h.x_facet);
-#else
-  /* (A/B: the two subtractions per collision instead of two values kept per cell;
-   * r03/experiments/collision_loop_head_ab.log) */
-  (void)x_lo_open;
-  (void)y_lo_open;
-  calc_distance_to_facet(h.x, h.y, h.omega_x, h.omega_y, h.speed, h.u_x_inv, h.u_y_inv,
-                         e.x_lo, e.x_hi, e.y_lo, e.y_hi, distance_to_facet, h.x_facet);
-#endif
   const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
   const double distance_to_census = h.speed * h.dt_to_census;
   h.distance = distance_to_collision;
@@ -795,15 +866,7 @@ __device__ __forceinline__ void load_targets(History& h, const SolveArgs& a) {
 
 template <bool kWatchdog = true>
 __device__ __forceinline__ void decide(History& h, const SolveArgs& a) {
-#if defined(NEUTRAL_EXP_COMPUTED_EDGES)
-  /* timing experiment only: no edge loads */
-  const double ew = 1.0 / (double)a.nx;
-  const int ex = h.cellx - a.x_off + a.pad;
-  const int ey = h.celly - a.y_off + a.pad;
-  decide<kWatchdog>(h, a, CellEdges{ex * ew, (ex + 1) * ew, ey * ew, (ey + 1) * ew});
-#else
   decide<kWatchdog>(h, a, load_edges(a, h.cellx, h.celly));
-#endif
 }
 
 /* collision_event, omp3/neutral.c:209-300.  Returns true when the particle died.
@@ -940,11 +1003,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
      * logic on the two axes' booleans it comes out as 0/1 values in vector registers
      * combined by and / compare / select again -- 25 vector instructions where these
      * are 9. */
-#if defined(NEUTRAL_NO_AXIS_SELECT)
-    reflect = xf ? (h.cellx == h.wall_x) : (h.celly == h.wall_y);
-    ncellx = h.cellx + ((xf & !reflect) ? h.step_x : 0);
-    ncelly = h.celly + ((!xf & !reflect) ? h.step_y : 0);
-#elif !defined(NEUTRAL_NO_LANE_MASKS)
     /* ... or the logic is done where it is free: the comparisons' lane masks are combined
      * on the scalar unit and come back as select conditions (two compares and two selects
      * in the vector unit) */
@@ -955,16 +1013,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     reflect = __builtin_amdgcn_inverse_ballot_w64(m_reflect);
     ncellx = h.cellx + (__builtin_amdgcn_inverse_ballot_w64(m_xf & ~m_wall_x) ? h.step_x : 0);
     ncelly = h.celly + (__builtin_amdgcn_inverse_ballot_w64(~m_xf & ~m_wall_y) ? h.step_y : 0);
-#else
-    const int cell = xf ? h.cellx : h.celly;
-    const int wall = xf ? h.wall_x : h.wall_y;
-    reflect = (cell == wall);
-    const int along = xf ? h.step_x : h.step_y;
-    const int step = reflect ? 0 : along;
-    const int dx = xf ? step : 0;
-    ncellx = h.cellx + dx;
-    ncelly = h.celly + (step - dx);
-#endif
   } else {
     const double omega = xf ? h.omega_x : h.omega_y;
     const int cell = xf ? h.cellx : h.celly;
@@ -996,18 +1044,9 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
       ex = (ex < ex_lo) ? ex_lo : ((ex > ex_hi) ? ex_hi : ex);
       ey = (ey < ey_lo) ? ey_lo : ((ey > ey_hi) ? ey_hi : ey);
     }
-#if defined(NEUTRAL_EXP_NO_EDGE_LOADS)
-    /* timing experiment only (uniform meshes): the edges worked out, not loaded */
-    edge_ahead_x = (double)ex * (1.0 / (double)a.nx);
-    edge_ahead_y = (double)ey * (1.0 / (double)a.ny);
-#else
     edge_ahead_x = edge_x<kComputedEdges>(a, ex);
     edge_ahead_y = edge_y<kComputedEdges>(a, ey);
-#endif
   }
-#if defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
-  const double new_density = h.local_density; /* timing experiment only (uniform decks) */
-#else
   if (kCarryTargets) {
     __builtin_amdgcn_sched_barrier(0); /* (the edge loads are issued by here) */
   }
@@ -1026,7 +1065,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   if (!Tally::kUniformDensity) {
     new_density = *mesh_element(a.density, dens_y * a.nx + dens_x);
   }
-#endif
 
   const double distance_to_facet = h.distance;
   if (kCachedReciprocals) {
@@ -1074,9 +1112,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     /* the position is final before the (rare) reflection turns the direction round: sunk
      * below that branch, old and new direction are both live across it and every trip of
      * the facet loop pays four 64-bit register copies for the one in a thousand that turns */
-#if !defined(NEUTRAL_NO_POSITION_PIN)
     asm volatile("" : "+v"(h.x), "+v"(h.y));
-#endif
   }
 
   /* 1/((-omega)*speed) = -(1/(omega*speed)) bit for bit (IEEE multiplication and
@@ -1086,9 +1122,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   if (kCarryTargets) {
     h.cellx = ncellx;
     h.celly = ncelly;
-#if defined(NEUTRAL_NO_AXIS_SELECT) || defined(NEUTRAL_NO_LANE_MASKS)
-    m_reflect = __builtin_amdgcn_ballot_w64(reflect);
-#endif
     if (__builtin_expect(m_reflect != 0, 0)) { /* wave-uniform: most trips of the facet loop skip it */
       h.omega_x = flip_x ? -h.omega_x : h.omega_x;
       h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
@@ -1123,20 +1156,15 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     calc_distance_to_targets(h.x, h.y, h.speed, h.u_x_inv, h.u_y_inv, h.target_x, h.target_y,
                              h.distance, h.x_facet);
     h.m_x_facet = __builtin_amdgcn_ballot_w64(h.x_facet != 0);
-#if defined(NEUTRAL_PIN_X_FACET)
-    asm volatile("" : "+v"(h.distance), "+v"(h.x_facet));
-#else
     /* (x_facet is not pinned with it: the comparison's lane mask serves the next trip's
      * selects as it is -- pinned, it is a 0/1 vector register and a compare per trip) */
     asm volatile("" : "+v"(h.distance));
-#endif
   }
 
   /* pin the two quotients above the wait for the density: left alone, the compiler
    * sinks both divides below the branch that consumes the load */
   asm volatile("" : "+v"(h.mfp_to_collision), "+v"(h.dt_to_census));
 
-#if !defined(NEUTRAL_EXP_NO_DENSITY_RELOAD)
   if constexpr (Tally::kUniformDensity) {
     if (__builtin_expect(tally.m_outside == 0, 1)) {
       return; /* (no lane outside the window: asked of the wave first, it is a scalar test) */
@@ -1146,7 +1174,6 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     }
     new_density = *mesh_element(a.density, dens_y * a.nx + dens_x); /* (rare, dependent) */
   }
-#endif
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
     macroscopic_from_density<kChecked>(h);

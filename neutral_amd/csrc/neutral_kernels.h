@@ -32,19 +32,14 @@ struct ParticleView {
  * Sorted-by-tile access is random per particle, and a random 80-B record costs
  * two 64-B sectors where the SoA store costs eleven; the records are kept in
  * tile order from step to step and carry the particle id (the RNG key). */
-/* (experiment switch NEUTRAL_REC_ALIGN=128: one record per 128-byte line) */
-#ifndef NEUTRAL_REC_ALIGN
-#define NEUTRAL_REC_ALIGN 16
-#endif
-struct alignas(NEUTRAL_REC_ALIGN) ParticleRec {
+struct alignas(16) ParticleRec {
   double x, y, omega_x, omega_y, energy, weight, dt_to_census, mfp_to_collision;
   int cellx, celly;
   unsigned id; /* index in the SoA store = global id - pid_base */
   int dead;
 };
-constexpr int kParticleRecBytes = 80; /* what a record holds, whatever its alignment pads it to */
-static_assert(sizeof(ParticleRec) == (NEUTRAL_REC_ALIGN > 80 ? NEUTRAL_REC_ALIGN : 80),
-              "ParticleRec holds 80 bytes");
+constexpr int kParticleRecBytes = 80;
+static_assert(sizeof(ParticleRec) == kParticleRecBytes, "ParticleRec holds 80 bytes");
 
 /* What a history suspended MID-CHAIN by the collision stage's time slicing needs
  * beyond its record: the RNG counter, the deposition not yet tallied
@@ -88,6 +83,26 @@ struct StepCounters {
   unsigned long long nrequeued; /* time-slice swaps of the collision stage (queue mode) */
   unsigned long long ncollide_passes; /* wave-level COLLIDE passes of the regroup kernel */
   unsigned long long nsteals; /* collision stage: rings a wave took half the waiting histories of */
+  unsigned long long steal_refused; /* collision stage: waves that found a CU list of more than
+                                       kCuWavesMax entries and therefore stole nothing (the key
+                                       read from the hardware does not name one CU: see StealWork) */
+};
+
+/* Device workspace of the collision stage's work stealing (neutral_kernels.hip): the control
+ * word of every wave's ring, who is reading from which ring, and the list of waves per CU key.
+ * It belongs to the tiled workspace (TiledArgs::steal), is handed to the kernel in SolveArgs and
+ * is reset by one kernel on the launch's own stream before every collision stage. */
+constexpr int kRingCtlSlots = 8192;  /* waves of a launch (4 096 on an MI355X) */
+constexpr int kCuSlots = 4096;       /* (xcc 4 bits, se 3, sh 1, cu 4) */
+constexpr int kCuWavesMax = 16;
+struct StealWork {
+  unsigned long long ring_ctl[kRingCtlSlots]; /* head << 32 | waiting */
+  /* waves that are reading entries out of a ring they have just taken from: the owner waits
+   * for zero before it writes into its ring (hand-back) or re-uses it for what it steals */
+  unsigned ring_readers[kRingCtlSlots];
+  unsigned cu_count[kCuSlots];
+  unsigned cu_members[kCuSlots * kCuWavesMax];
+  unsigned overfull; /* a CU key collected more than kCuWavesMax waves: nobody steals */
 };
 
 struct SolveArgs {
@@ -149,15 +164,11 @@ struct SolveArgs {
   int tile_shift;            /* log2 of the tile edge in cells (4..7) */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
   double* susp_track;        /* ... their pending weight * path length (scalar flux only) */
-  /* tiled variant: a history that ends also writes its final state to the SoA store
-   * `p` at its id, so the interface's arrays are current when solve_transport_2d
-   * returns (0: lazy export, the records are written back on demand) */
-  int export_soa;
-  /* [device] copy of `p` for the kernels whose hot loop has no registers to spare for
-   * eleven more array pointers (the collision stage): read where a history ends */
-  const ParticleView* export_view;
   int steal_min;              /* collision stage: waiting histories a ring must hold to be taken
                                  from by a CU-mate (0: no stealing; NEUTRAL_STEAL_MIN) */
+  StealWork* steal;           /* [device] rings' control words and CU lists (null: no stealing) */
+  int steal_delay;            /* test knob: sleeps of a thief between its take and its copy
+                                 (NEUTRAL_STEAL_DELAY; 0 in production) */
   int occupancy_rows;         /* collision stage: workgroups per CU resident together, among
                                  which the kernel picks how many work (0: all) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
@@ -196,11 +207,10 @@ struct TiledArgs {
    * nparticles. */
   int sort_end;
   int mirror_end;
-  int slots_by_id;         /* 1: the step is followed by the write-back, so the kernels that
-                              place a record (pass 0, copy_inactive) note slot_of_id[id] (a
-                              scattered 4-B store each, hidden in the stream kernel); 0: they
-                              do not (lazy write-back: whoever writes back reads the ids out
-                              of the records first; decomposed stores keep id_out[slot]) */
+  int slots_by_id;         /* 1: the kernels that place a record (pass 0, copy_inactive) note
+                              slot_of_id[id] -- a scattered 4-B store each, hidden in the stream
+                              kernel: what the write-back goes by, in a step or on demand; 0: a
+                              decomposed store, which keeps id_out[slot] instead */
   unsigned* order;         /* nparticles: record indices sorted by tile (pass 0: into rec_in,
                               the dead last; later passes: the migrants, into rec_out) */
   unsigned* tile_count;    /* nsort + 2: histogram of the counting sort (zero between uses) */
@@ -210,6 +220,19 @@ struct TiledArgs {
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
   double* susp_track;      /* nparticles, only with the scalar-flux tally (else null) */
+  StealWork* steal;        /* the collision stage's rings and CU lists (neutral_kernels.hip) */
+  /* The stream kernel's tile queues (neutral_tiled.hip, "asynchronous tile queue"): per tile an
+   * append-only log of record slots whose histories left the tally window they were streaming
+   * under with far to go and have reached this tile.  Producers reserve places with an atomic add
+   * on queue_tail and store the slot (kQueueEmpty until then); workgroups claim ranges with a
+   * compare-and-swap on queue_head and stream them under a window centred on the tile -- inside
+   * the SAME launch: no sort, no further pass.  A tile that receives more than queue_capacity
+   * in one launch overflows into the pass mechanism (kRecMigrate, sorted by the next pass).
+   * null: no queues, every migrant waits for the next pass. */
+  unsigned* queue_entries; /* ntiles * queue_capacity */
+  unsigned* queue_tail;    /* ntiles: places reserved in this launch (may exceed the capacity) */
+  unsigned* queue_head;    /* ntiles: places claimed by workgroups */
+  unsigned queue_capacity;
   /* finer bucketed index for the collision stage (identical tables only; null: none) */
   const unsigned short* fine_index;
   int fine_index_n;
@@ -233,7 +256,6 @@ struct TiledArgs {
   int ntiles;
   int reach_classes;       /* 1, or 4: records are sorted by (tile, reach class) -- sparse
                               problems, neutral_history.h: reach_class */
-  int reach_longest_first; /* the classes of a tile in descending order (default) */
   int nsort;               /* buckets of the counting sort: ntiles * reach_classes (+ the dead) */
   int max_chunks;
 };
@@ -293,16 +315,18 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
                                  unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
                                  int n, hipStream_t stream);
 /* slot_of_id: where each id's record is (TiledArgs::slot_of_id) */
-/* first_inactive [device]: first slot of the particles that were dead when the step began --
- * given when the arrays were current then, so that those are left alone; null: every record */
+/* Records in slots from a boundary on belong to particles whose final state the arrays hold
+ * already and are left alone (the random access to them is what the pass is bound by):
+ * first_inactive [device] -- the first slot of the particles that were dead when the step
+ * began, given when the arrays were current then -- or, when that is null, final_from [host
+ * value]: the graveyard's first slot at the time the arrays were last current (0xFFFFFFFF:
+ * every record is written). */
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream,
                                  const int* abort_flag = nullptr,
-                                 const unsigned* first_inactive = nullptr);
+                                 const unsigned* first_inactive = nullptr,
+                                 unsigned final_from = 0xFFFFFFFFu);
 const unsigned* tiled_first_inactive(const TiledArgs& t);
-/* slot_of_id from the ids in the records (after steps that did not keep it) */
-hipError_t launch_invert_ids(const ParticleRec* rec, unsigned* slot_of_id, int n,
-                             hipStream_t stream);
 /* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
  * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
  * behind the first_slot records, holes closed at the end of the step (t.rec_out ->

@@ -41,21 +41,7 @@ constexpr int kBlock = 256;
  * since the range tests that cannot fire left the event bodies, and runs at 4 with 28 B
  * of scratch in cold paths (-2.5 % against 3 waves); its other instantiations (two
  * distinct tables, scalar flux: 143-150 VGPRs) stay at 3. */
-#ifndef NEUTRAL_K1_WAVES
-#define NEUTRAL_K1_WAVES 3
-#endif
-#ifndef NEUTRAL_K2_WAVES
-#define NEUTRAL_K2_WAVES 3
-#endif
-/* (experiment switch: NEUTRAL_NO_COLD_ARGS keeps every argument in registers) */
-#if defined(NEUTRAL_NO_COLD_ARGS)
-#define NEUTRAL_COLD_ARGS(a) (a)
-#else
 #define NEUTRAL_COLD_ARGS(a) (kQueue ? cold_args() : (a))
-#endif
-#ifndef NEUTRAL_K2_QUEUE_WAVES
-#define NEUTRAL_K2_QUEUE_WAVES 4
-#endif
 
 /* ---- K0: injection --------------------------------------------------------- */
 
@@ -179,7 +165,7 @@ hipError_t launch_inject_filtered(const InjectArgs& a, unsigned* keys, unsigned*
 /* ---- K1: over-particle history kernel -------------------------------------- */
 
 template <bool kSameTables, bool kFlux, bool kChecked>
-__global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(SolveArgs a) {
+__global__ __launch_bounds__(kBlock, 3) void history_kernel(SolveArgs a) {
   const int pid = blockIdx.x * kBlock + threadIdx.x;
 
   unsigned nfacets = 0;
@@ -255,17 +241,8 @@ __global__ __launch_bounds__(kBlock, NEUTRAL_K1_WAVES) void history_kernel(Solve
  * wave reaches that state without waiting for any other.
  */
 constexpr int kQueueChunk = 128; /* ids a wave claims per atomic when work is plentiful */
-#ifndef NEUTRAL_QUEUE_CHUNK_MIN
-#define NEUTRAL_QUEUE_CHUNK_MIN 8
-#endif
-#ifndef NEUTRAL_REFILL_MIN
-#define NEUTRAL_REFILL_MIN 3
-#endif
-#ifndef NEUTRAL_COLLIDE_MIN
-#define NEUTRAL_COLLIDE_MIN 48
-#endif
-constexpr int kRefillMin = NEUTRAL_REFILL_MIN;   /* REFILL pass once this many lanes are empty */
-constexpr int kCollideMin = NEUTRAL_COLLIDE_MIN; /* COLLIDE pass once this many lanes wait */
+constexpr int kRefillMin = 3;   /* REFILL pass once this many lanes are empty */
+constexpr int kCollideMin = 48; /* COLLIDE pass once this many lanes wait */
 
 enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothing = 3 };
 
@@ -291,30 +268,18 @@ enum Want : int { kWantRefill = 0, kWantStream = 1, kWantCollide = 2, kWantNothi
  * every kSlicePasses collisions.  Histories execute exactly the events they
  * would execute unsliced: the record, the RNG counter and the pending
  * deposition are all that survives a loop head (see resume()). */
-#ifndef NEUTRAL_SLICE_PASSES
-#define NEUTRAL_SLICE_PASSES 64 /* (128 or 256 measure the same with the rings evened out by stealing) */
-#endif
-constexpr int kSlicePasses = NEUTRAL_SLICE_PASSES;
+constexpr int kSlicePasses = 64;
 /* Measured (profiles/r01g/ablate_shares.log, ablate_slicewindow.log):
  *  - slicing THROUGHOUT a share beats slicing only near its end by 9-17 %: lanes
  *    that swap together stay at the same collision count, hence at similar
  *    energies, and their cs-table probes fall into few cache lines; lanes refilled
  *    one by one drift apart and every probe becomes 64 separate L1 requests.
- *    NEUTRAL_SLICE_WINDOW > 0 restricts slicing to the last so-many waiting
- *    histories (experiment knob; 0 = throughout).
  *  - strided or contiguous shares make no difference.
  *  - with tens of generations per wave (scatter, split at 1e8: 30 000 histories per
  *    wave) the first-come-first-served queue of variant 1 is 3-6 % faster than
  *    slicing (no record round trips, and its ragged end is under 1 % of the
  *    run), so shares above kPoolMaxShare keep it. */
-#ifndef NEUTRAL_SLICE_WINDOW
-#define NEUTRAL_SLICE_WINDOW 0
-#endif
-constexpr int kSliceWindow = NEUTRAL_SLICE_WINDOW;
-#ifndef NEUTRAL_POOL_MAX_SHARE
-#define NEUTRAL_POOL_MAX_SHARE 2048
-#endif
-constexpr int kPoolMaxShare = NEUTRAL_POOL_MAX_SHARE;
+constexpr int kPoolMaxShare = 2048;
 constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is valid */
 
 /* ---- the waves of a CU finish together: stealing between their rings (pooled mode) ---
@@ -329,49 +294,28 @@ constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is 
  * CU, as often as there is one to take from, and the sixteen waves of a CU end within a
  * slice of each other with all of them present until then.
  *   * Who shares a CU is read from the hardware (HW_ID, XCC_ID): every wave enters itself
- *     in its CU's list at the start of the launch.  Same CU on purpose: a record a wave
- *     wrote (write-through L1, the CU's own) is seen by its CU-mates after the writer's
- *     wait for its stores, without the L2 write-back and invalidate an exchange between
- *     the chip's eight XCDs would need at every slice.
+ *     in the list of its key at the start of the launch.  Same CU on purpose: what a wave
+ *     stored went through the L1 the thief reads through, and lies in the L2 both share.
+ *     The key is a LOCALITY hint, not what correctness rests on:
+ *       - every successful take is followed by an agent-scope acquire (the thief's L1 holds
+ *         nothing stale of the records and ring words it is about to read);
+ *       - a key that collects more than kCuWavesMax waves does not name one CU (the decode is
+ *         wrong on this part, or the launch is not the shape the lists assume): the launch
+ *         then steals nothing (StealWork::overfull; counted in StepCounters::steal_refused
+ *         and NeutralHipStepStats::steals_refused);
+ *       - an owner does not write into its ring while anybody reads from it (ring_readers).
  *   * A ring's control word (head << 32 | waiting) lives in memory: its owner takes from the
  *     head by compare-and-swap and appends by an atomic add (the tail -- head + waiting --
  *     moves only when the owner appends, so it is the owner's own); a thief takes from the
  *     head by compare-and-swap.  The entries a take frees lie behind the tail by as many
- *     places as histories left the ring for good, so nobody writes where somebody reads.
+ *     places as histories left the ring for good, and the owner waits for the thief's copy
+ *     to be over before it stores into its ring again, so nobody writes where somebody reads.
  *   * Histories are independent and carry their whole state in their record (+ SuspendExtra),
- *     so which wave finishes a history changes nothing it computes. */
-constexpr int kRingCtlSlots = 8192;  /* waves of a launch (4 096 on an MI355X) */
-constexpr int kCuSlots = 4096;       /* (xcc 4 bits, se 3, sh 1, cu 4) */
-constexpr int kCuWavesMax = 16;
-#ifndef NEUTRAL_STEAL_MIN
-#define NEUTRAL_STEAL_MIN 96
-#endif
-constexpr int kStealMin = NEUTRAL_STEAL_MIN; /* waiting histories a ring must hold to be taken from
+ *     so which wave finishes a history changes nothing it computes.
+ *   * The words live in the tiled workspace (StealWork, neutral_kernels.h): one per workspace,
+ *     reset by steal_reset_kernel on the launch's own stream -- not process-wide symbols. */
+constexpr int kStealMin = 96; /* waiting histories a ring must hold to be taken from
                                                (SolveArgs::steal_min; 0: no stealing) */
-__device__ unsigned long long g_ring_ctl[kRingCtlSlots];
-/* waves that are reading entries out of a ring they have just taken from: a wave that re-uses
- * its own (empty) ring for what IT takes from somebody waits until this is zero.  (A reader
- * waits for nobody, so the wait ends; in practice the ring has been empty for milliseconds
- * before its owner turns thief, and a copy takes microseconds.) */
-__device__ unsigned g_ring_readers[kRingCtlSlots];
-__device__ unsigned g_cu_count[kCuSlots];
-__device__ unsigned g_cu_members[kCuSlots * kCuWavesMax];
-/* ... and the same per XCD (the CUs of an XCD share its L2): where a wave looks when its own
- * CU has nothing left to take.  What it takes there was written on another CU: it is in the
- * L2 the two share (stores are write-through and complete before their ring says that they
- * wait), and the thief drops what its own L1 may still hold of those lines (an acquire at
- * agent scope: buffer_inv) before it reads any of it.  Built, correct (the steal test passes
- * with it) and SLOWER: csp collision stage 332 against 326 ms per 10 steps, 178 against 172 at
- * 5e7 particles (profiles/r03/experiments/collision_wave_exit_times.log) -- histories that
- * change CU arrive cold, and the CUs of an XCD end within 2 % of each other anyway.  Off
- * (NEUTRAL_STEAL_XCD=1: the experiment). */
-constexpr int kXcdSlots = 16;
-constexpr int kXcdWavesMax = 1024;
-__device__ unsigned g_xcd_count[kXcdSlots];
-__device__ unsigned g_xcd_members[kXcdSlots * kXcdWavesMax];
-#ifndef NEUTRAL_STEAL_XCD
-#define NEUTRAL_STEAL_XCD 0
-#endif
 
 __device__ __forceinline__ unsigned cu_key() {
   /* HW_ID (s_getreg id 4): cu [11:8], sh [12], se [15:13]; XCC_ID (id 20): [3:0] */
@@ -379,11 +323,29 @@ __device__ __forceinline__ unsigned cu_key() {
   const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
   return ((hw >> 8) & 0xFFu) | ((xcc & 0xFu) << 8);
 }
-__device__ __forceinline__ unsigned long long ring_ctl_load(int wave) {
-  return __hip_atomic_load(&g_ring_ctl[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned long long ring_ctl_load(StealWork* sw, int wave) {
+  return __hip_atomic_load(&sw->ring_ctl[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned wave_uniform(unsigned v) {
   return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+/* the lists start empty, every entry invalid, nobody reading (one launch per collision stage) */
+__global__ __launch_bounds__(256) void steal_reset_kernel(StealWork* sw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < kCuSlots * kCuWavesMax) {
+    sw->cu_members[i] = 0xFFFFFFFFu;
+  }
+  if (i < kCuSlots) {
+    sw->cu_count[i] = 0u;
+  }
+  if (i < kRingCtlSlots) {
+    sw->ring_readers[i] = 0u;
+    sw->ring_ctl[i] = 0ull;
+  }
+  if (i == 0) {
+    sw->overfull = 0u;
+  }
 }
 
 
@@ -418,17 +380,12 @@ template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
-    store_record(h, a, a.rec[pid], state);
+    /* (write-through: a record that ends here shares its 128-byte lines with records that are
+     * handed back to a ring and may be taken over by another wave -- no line of the record array
+     * is left dirty in an L2 by this kernel: neutral_history.h) */
+    store_record_through(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
-    if (a.export_view) {
-      /* the interface's arrays stay current.  The eleven array pointers are fetched
-       * here, from memory: as kernel arguments they would be live through the
-       * collision loop and push it into scratch (100 B per lane, -20 %) */
-      const ParticleView* pv = a.export_view;
-      asm volatile("" : "+s"(pv)); /* (not foldable back into the kernel arguments) */
-      store_particle_view(h, *pv, (int)h.id);
-    }
   } else {
     store_particle(h, a, pid);
   }
@@ -438,23 +395,15 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
  * colliders mixed (parked lanes make occupancy matter: 4 waves/SIMD, small
  * spill); kQueue = true: the collision stage of the tiled pipeline, histories
  * suspended by the stream kernel, colliders only (3 waves/SIMD, no spill). */
-#if defined(NEUTRAL_EXP_WAVE_TIMES)
-__device__ unsigned long long g_wave_times[10] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0, 0, 0};
-__device__ unsigned long long g_cu_last_exit[4096];
-#endif
 
 template <bool kSameTables, bool kQueue, bool kFlux, bool kChecked>
-__global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux && !kChecked) ? NEUTRAL_K2_QUEUE_WAVES : 3)
-                                             : NEUTRAL_K2_WAVES)
+__global__ __launch_bounds__(kBlock, kQueue ? ((kSameTables && !kFlux && !kChecked) ? 4 : 3)
+                                             : 3)
 void history_regroup_kernel(SolveArgs a) {
   unsigned nfacets = 0;
   unsigned ncollisions = 0;
   unsigned nprocessed = 0;
   unsigned ncensus = 0;
-#if defined(NEUTRAL_EXP_WAVE_TIMES)
-  const unsigned long long exp_t0 = wall_clock64();
-  const unsigned long long exp_c0 = clock64();
-#endif
 
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
@@ -515,7 +464,7 @@ void history_regroup_kernel(SolveArgs a) {
    * waves getting two generations each while the other SIMDs idle. */
   const int nwaves = block_count * (kBlock / 64);
   int chunk = (nwork + nwaves - 1) / nwaves;
-  chunk = (chunk < NEUTRAL_QUEUE_CHUNK_MIN) ? NEUTRAL_QUEUE_CHUNK_MIN : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
+  chunk = (chunk < 8) ? 8 : ((chunk > kQueueChunk) ? kQueueChunk : chunk);
 
   History h;
   int pid = -1;
@@ -555,31 +504,31 @@ void history_regroup_kernel(SolveArgs a) {
 
   /* pooled mode (the collision stage): the wave's strided share of the queue is its
    * ring; all wave-uniform */
-  const bool pooled = kQueue && a.susp && ((long long)nwork <= (long long)nwaves * kPoolMaxShare) &&
+  const bool pooled = kQueue && a.susp && a.steal && ((long long)nwork <= (long long)nwaves * kPoolMaxShare) &&
                       nwaves <= kRingCtlSlots;
   const int gw = block_index * (kBlock / 64) + (int)(threadIdx.x >> 6);
   const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
-  /* the ring's control word is g_ring_ctl[gw] (above); these are the owner's own view */
+  /* the ring's control word is a.steal->ring_ctl[gw] (StealWork); these are the owner's own view */
   unsigned w_steals = 0;
+  unsigned w_steal_refused = 0;
   int ring_tail = 0;      /* ring position the next history handed back goes to (head + waiting) */
   int ring_count = share; /* histories waiting in the ring, as last seen (a CU-mate may have taken some) */
   int slice = 0;
   const unsigned my_cu = pooled ? cu_key() : 0u;
   if (pooled && (threadIdx.x & 63) == 0) {
-    g_ring_ctl[gw] = (unsigned long long)(unsigned)share; /* head 0 */
+    StealWork* const sw = a.steal;
+    atomicExch(&sw->ring_ctl[gw], (unsigned long long)(unsigned)share); /* head 0 */
     if (a.steal_min > 0 && share > 0) {
-      /* (the ring's word is in memory before the wave shows up in its CU's list) */
-      __threadfence_block();
-      const unsigned slot = atomicAdd(&g_cu_count[my_cu], 1u);
+      /* (the ring's word is in memory -- an atomic: at the L2 -- before the wave shows up in
+       * its CU's list) */
+      const unsigned slot = atomicAdd(&sw->cu_count[my_cu], 1u);
       if (slot < (unsigned)kCuWavesMax) {
-        g_cu_members[my_cu * kCuWavesMax + slot] = (unsigned)gw;
-      }
-      if (NEUTRAL_STEAL_XCD) {
-        const unsigned xcd = my_cu >> 8;
-        const unsigned xslot = atomicAdd(&g_xcd_count[xcd], 1u);
-        if (xslot < (unsigned)kXcdWavesMax) {
-          g_xcd_members[xcd * kXcdWavesMax + xslot] = (unsigned)gw;
-        }
+        __hip_atomic_store(&sw->cu_members[my_cu * kCuWavesMax + slot], (unsigned)gw, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        /* more waves under one key than a CU holds: the key does not name a CU, and what
+         * stealing assumes about its members does not hold -- nobody steals in this launch */
+        __hip_atomic_store(&sw->overfull, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -591,6 +540,11 @@ void history_regroup_kernel(SolveArgs a) {
      * of its younger CU-mates' full ones; 48.5 against 46.5 ms per 10 steps) */
     const unsigned steal_min = (unsigned)a.steal_min;
     if (!pooled || steal_min == 0 || (unsigned)share < 2u * steal_min) {
+      return false;
+    }
+    StealWork* const sw = cold_args().steal;
+    if (__hip_atomic_load(&sw->overfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      w_steal_refused = 1; /* (a key of more than kCuWavesMax waves: see StealWork) */
       return false;
     }
     const int lane = (int)(threadIdx.x & 63);
@@ -605,7 +559,7 @@ void history_regroup_kernel(SolveArgs a) {
           /* (the launch starts with every entry invalid; a wave that has only counted itself
            * in so far is not looked at) */
           if (victim < (unsigned)nwaves && (int)victim != gw) {
-            ctl = ring_ctl_load((int)victim);
+            ctl = ring_ctl_load(sw, (int)victim);
           }
         }
         const unsigned waiting = (unsigned)ctl;
@@ -628,20 +582,11 @@ void history_regroup_kernel(SolveArgs a) {
       return best;
     };
     for (int attempt = 0; attempt < 4; ++attempt) {
-      unsigned mates = __hip_atomic_load(&g_cu_count[my_cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned mates = __hip_atomic_load(&sw->cu_count[my_cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       mates = (mates > (unsigned)kCuWavesMax) ? (unsigned)kCuWavesMax : mates;
       int v = 0;
       unsigned v_head = 0;
-      unsigned best = fullest(&g_cu_members[my_cu * kCuWavesMax], mates, v, v_head);
-      bool other_cu = false;
-      if ((best < steal_min || best < 2u) && NEUTRAL_STEAL_XCD) {
-        /* nothing on this CU: the other CUs of the XCD */
-        const unsigned xcd = my_cu >> 8;
-        unsigned n = __hip_atomic_load(&g_xcd_count[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n = (n > (unsigned)kXcdWavesMax) ? (unsigned)kXcdWavesMax : n;
-        best = fullest(&g_xcd_members[xcd * kXcdWavesMax], n, v, v_head);
-        other_cu = true;
-      }
+      const unsigned best = fullest(&sw->cu_members[my_cu * kCuWavesMax], mates, v, v_head);
       if (best < steal_min || best < 2u) {
         return false;
       }
@@ -657,21 +602,25 @@ void history_regroup_kernel(SolveArgs a) {
       if (lane == 0) {
         const unsigned long long seen = ((unsigned long long)v_head << 32) | best;
         const unsigned long long next = ((unsigned long long)new_head << 32) | (best - take);
-        atomicAdd(&g_ring_readers[v], 1u);
-        won = (atomicCAS(&g_ring_ctl[v], seen, next) == seen) ? 1u : 0u;
+        atomicAdd(&sw->ring_readers[v], 1u);
+        won = (atomicCAS(&sw->ring_ctl[v], seen, next) == seen) ? 1u : 0u;
         if (!won) {
-          atomicSub(&g_ring_readers[v], 1u);
+          atomicSub(&sw->ring_readers[v], 1u);
         }
       }
       if (!wave_uniform(won)) {
         continue; /* (its owner or another thief was quicker: look again) */
       }
-      if (other_cu) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* (nothing stale of it in this CU's L1) */
-      }
+      /* every take: nothing stale in this CU's L1 of what the wave reads next, whichever CU
+       * its owner ran on (the records themselves are read with loads that bypass the L1) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       /* (nobody is still reading what was taken from THIS wave's ring earlier) */
-      while (__hip_atomic_load(&g_ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      while (__hip_atomic_load(&sw->ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __builtin_amdgcn_s_sleep(2);
+      }
+      /* (test knob: a slow thief -- the owner of the ring it reads must wait for it) */
+      for (int d = cold_args().steal_delay; d > 0; --d) {
+        __builtin_amdgcn_s_sleep(64);
       }
       /* the entries [v_head, v_head + take) of v's ring are this wave's now */
       for (unsigned i = (unsigned)lane; i < take; i += 64u) {
@@ -679,19 +628,17 @@ void history_regroup_kernel(SolveArgs a) {
         pos = (pos >= (unsigned)v_share) ? pos - (unsigned)v_share : pos;
         const unsigned e = __hip_atomic_load(a.queue + ((size_t)v + (size_t)pos * (size_t)nwaves),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.queue[(size_t)gw + (size_t)i * (size_t)nwaves] = e; /* this wave's ring, from position 0 */
+        __hip_atomic_store(a.queue + ((size_t)gw + (size_t)i * (size_t)nwaves), e, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT); /* this wave's ring, from position 0 */
       }
-      __threadfence_block();
+      drain_stores(); /* (the loads have returned, the copies are where a later thief sees them) */
       if (lane == 0) {
-        atomicSub(&g_ring_readers[v], 1u); /* (the loads above have returned: their values were stored) */
-        atomicExch(&g_ring_ctl[gw], (unsigned long long)take); /* head 0, `take` waiting */
+        atomicSub(&sw->ring_readers[v], 1u);
+        atomicExch(&sw->ring_ctl[gw], (unsigned long long)take); /* head 0, `take` waiting */
       }
       ring_tail = ((int)take >= share) ? (int)take - share : (int)take;
       ring_count = (int)take;
       w_steals++;
-#if defined(NEUTRAL_EXP_WAVE_TIMES)
-      if (lane == 0) atomicAdd(&g_wave_times[8], 1ull);
-#endif
       return true;
     }
     return false;
@@ -759,7 +706,8 @@ void history_regroup_kernel(SolveArgs a) {
       /* ---- REFILL pass, pooled: the histories at the front of the ring ---- */
       unsigned taken = 0, head_was = 0, left = 0;
       if ((threadIdx.x & 63) == 0) {
-        unsigned long long seen = ring_ctl_load(gw);
+        StealWork* const sw = cold_args().steal;
+        unsigned long long seen = ring_ctl_load(sw, gw);
         for (;;) {
           const unsigned waiting = (unsigned)seen;
           head_was = (unsigned)(seen >> 32);
@@ -771,7 +719,7 @@ void history_regroup_kernel(SolveArgs a) {
           unsigned nh = head_was + taken;
           nh = (nh >= (unsigned)share) ? nh - (unsigned)share : nh;
           const unsigned long long next = ((unsigned long long)nh << 32) | left;
-          const unsigned long long old = atomicCAS(&g_ring_ctl[gw], seen, next);
+          const unsigned long long old = atomicCAS(&sw->ring_ctl[gw], seen, next);
           if (old == seen) {
             break;
           }
@@ -784,17 +732,19 @@ void history_regroup_kernel(SolveArgs a) {
       const int rank = lane_rank(m_refill);
       if (want == kWantRefill && rank < n_take) {
         const SolveArgs c = NEUTRAL_COLD_ARGS(a);
-        const unsigned e = *ring_slot(ring_head + rank);
+        /* (ring words and records may have been written by another wave of this launch -- the
+         * owner's own hand-back, a CU-mate it took them from: loads that bypass the L1) */
+        const unsigned e = __hip_atomic_load(ring_slot(ring_head + rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pid = (int)(e & ~kRequeued);
-        load_record(h, c, c.rec[pid]);
+        SuspendExtra x; /* (asked for with the record, one wait for both; looked at if it is valid) */
+        load_record_through(h, c, c.rec[pid], &c.susp[pid], x);
         resume<kSameTables, kChecked>(h, c, ix); /* counted as processed by the suspender */
         if (e & kRequeued) {
-          const SuspendExtra x = c.susp[pid];
           h.energy_deposition = x.energy_deposition;
           h.counter = x.counter;
           h.nevents = x.nevents;
           if (kFlux) {
-            h.track_length = c.susp_track[pid];
+            h.track_length = __hip_atomic_load(&c.susp_track[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         next_event(true);
@@ -877,8 +827,7 @@ void history_regroup_kernel(SolveArgs a) {
             want = (h.ev == kEvCollision) ? kWantCollide : kWantStream;
           }
         }
-        slice_ends = pooled && ++slice >= kSlicePasses && ring_count > 0 &&
-                     (kSliceWindow == 0 || ring_count <= kSliceWindow);
+        slice_ends = pooled && ++slice >= kSlicePasses && ring_count > 0;
         if (!kQueue || slice_ends || __ballot(want == kWantCollide) != m_collide) {
           break;
         }
@@ -899,31 +848,44 @@ void history_regroup_kernel(SolveArgs a) {
         slice = 0;
         const bool out = (want == kWantCollide);
         const unsigned long long m_out = __ballot(out);
+        StealWork* const sw = cold_args().steal;
+        /* a thief may still be copying entries out of this ring (its take came first, its
+         * loads may not have): nothing is stored into the ring while anybody reads from it.
+         * (One load per slice, asked for here and looked at below, behind the record stores
+         * -- which do not touch the ring; a copy takes microseconds.) */
+        unsigned readers = __hip_atomic_load(&sw->ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (out) {
           const SolveArgs c = NEUTRAL_COLD_ARGS(a);
-          store_record(h, c, c.rec[pid], kRecCollide);
+          /* write-through: whoever reads them next -- a lane of this wave, or a wave that
+           * takes them from this ring -- reads around its L1 (neutral_history.h) */
+          store_record_through(h, c, c.rec[pid], kRecCollide);
           SuspendExtra x;
           x.energy_deposition = h.energy_deposition;
           x.counter = h.counter;
           x.nevents = h.nevents;
-          c.susp[pid] = x;
+          store_through16(&c.susp[pid], x);
           if (kFlux) {
-            c.susp_track[pid] = h.track_length;
+            __hip_atomic_store(&c.susp_track[pid], h.track_length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        }
+        while (wave_uniform(readers) != 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          readers = __hip_atomic_load(&sw->ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (out) {
           /* outstanding histories never exceed the share: the slot is free */
-          *ring_slot(ring_tail + lane_rank(m_out)) = (unsigned)pid | kRequeued;
+          __hip_atomic_store(ring_slot(ring_tail + lane_rank(m_out)), (unsigned)pid | kRequeued, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
           want = kWantRefill;
         }
         const int n_out = __popcll(m_out);
         w_requeued += (unsigned)n_out;
         drained = false;
-        /* this wave -- possibly another lane of it -- or a wave of its CU reads these records
-         * and ring words back later: the stores complete first (workgroup scope: same CU,
-         * same L1), THEN the control word says that they wait */
-        __threadfence_block();
+        /* the stores have completed, THEN the control word says that they wait */
+        drain_stores();
         unsigned waiting_before = 0;
         if ((threadIdx.x & 63) == 0) {
-          waiting_before = (unsigned)atomicAdd(&g_ring_ctl[gw], (unsigned long long)n_out);
+          waiting_before = (unsigned)atomicAdd(&sw->ring_ctl[gw], (unsigned long long)n_out);
         }
         ring_count = (int)wave_uniform(waiting_before) + n_out;
         ring_tail += n_out;
@@ -939,7 +901,7 @@ void history_regroup_kernel(SolveArgs a) {
           if (kQueue && c.decomposed && outside_domain(h, c)) {
             /* into another rank's cells: the history waits to be sent (its RNG counter
              * travels in the record) */
-            store_record(h, c, c.rec[pid], kRecEmigrate);
+            store_record_through(h, c, c.rec[pid], kRecEmigrate);
             c.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, c.tiles_x, c.tile_shift);
             atomicAdd(c.emigrants, 1u);
             want = kWantRefill;
@@ -959,71 +921,11 @@ void history_regroup_kernel(SolveArgs a) {
     }
   }
   flush_counters(a, nprocessed, nfacets, ncollisions, ncensus);
-#if defined(NEUTRAL_EXP_WAVE_TIMES)
-  /* timing experiment only: when do the waves of the collision stage run out of work?
-   * (100-MHz wall clock; the last wave out prints first / mean / last exit of the launch) */
-  if (kQueue && (threadIdx.x & 63) == 0 && nwork > 4096) {
-    const unsigned long long now = wall_clock64();
-    const unsigned long long cnow = clock64();
-    if (now - exp_t0 > 100000ull) { /* (waves that lived > 1 ms: shader clocks per 100-MHz tick) */
-      atomicMax(&g_wave_times[7], (cnow - exp_c0) * 1000ull / (now - exp_t0));
-    }
-    atomicMin(&g_wave_times[0], now);
-    atomicMax(&g_wave_times[1], now);
-    atomicMax(&g_cu_last_exit[cu_key()], now);
-    atomicAdd(&g_wave_times[2], now - exp_t0);
-    atomicMin(&g_wave_times[4], exp_t0);
-    atomicAdd(&g_wave_times[5], (unsigned long long)w_collide_passes);
-    atomicMax(&g_wave_times[6], (unsigned long long)w_collide_passes);
-    const unsigned long long n = atomicAdd(&g_wave_times[3], 1ull) + 1ull;
-    if (n == (unsigned long long)nwaves) {
-      __threadfence();
-      const unsigned long long t0 = atomicMin(&g_wave_times[4], ~0ull);
-      const unsigned long long first = atomicMin(&g_wave_times[0], ~0ull);
-      const unsigned long long last = atomicMax(&g_wave_times[1], 0ull);
-      printf("collision stage: %d histories on %d waves: first wave out after %.3f ms, mean %.3f, last %.3f; "
-             "passes per wave mean %.0f max %llu; shader clock %.3f GHz; steals %llu\n", nwork, nwaves,
-             (double)(first - t0) * 1e-5, (double)g_wave_times[2] / (double)nwaves * 1e-5,
-             (double)(last - t0) * 1e-5, (double)g_wave_times[5] / (double)nwaves, g_wave_times[6],
-             (double)g_wave_times[7] * 1e-4, g_wave_times[8]);
-      {
-        /* (how many waves entered themselves in each CU's list: 16 everywhere in a full launch) */
-        unsigned lists = 0, full = 0, most = 0;
-        for (int i = 0; i < kCuSlots; ++i) {
-          const unsigned n_i = g_cu_count[i];
-          lists += n_i ? 1u : 0u;
-          full += (n_i == 16u) ? 1u : 0u;
-          most = (n_i > most) ? n_i : most;
-        }
-        printf("  CU lists: %u in use, %u of them with 16 waves, longest %u\n", lists, full, most);
-        unsigned long long cu_first = ~0ull, cu_last = 0, cu_sum = 0, ncu = 0;
-        unsigned long long xcd_last[16] = {0};
-        for (int i = 0; i < 4096; ++i) {
-          const unsigned long long e = g_cu_last_exit[i];
-          if (e) {
-            cu_first = (e < cu_first) ? e : cu_first;
-            cu_last = (e > cu_last) ? e : cu_last;
-            cu_sum += e - t0;
-            ncu++;
-            xcd_last[i >> 8] = (e > xcd_last[i >> 8]) ? e : xcd_last[i >> 8];
-          }
-          g_cu_last_exit[i] = 0;
-        }
-        printf("  a CU's last wave out: earliest CU %.3f ms, mean %.3f, latest %.3f; XCDs' last:", (double)(cu_first - t0) * 1e-5,
-               (double)cu_sum / (double)(ncu ? ncu : 1) * 1e-5, (double)(cu_last - t0) * 1e-5);
-        for (int x = 0; x < 8; ++x) printf(" %.2f", xcd_last[x] ? (double)(xcd_last[x] - t0) * 1e-5 : 0.0);
-        printf("\n");
-      }
-      g_wave_times[0] = ~0ull; g_wave_times[1] = 0; g_wave_times[2] = 0; g_wave_times[3] = 0;
-      g_wave_times[4] = ~0ull; g_wave_times[5] = 0; g_wave_times[6] = 0; g_wave_times[7] = 0;
-      g_wave_times[8] = 0;
-    }
-  }
-#endif
   if ((threadIdx.x & 63) == 0) {
     if (w_ncollisions) atomicAdd(&a.counters->ncollisions, w_ncollisions);
     if (w_requeued) atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
     if (w_steals) atomicAdd(&a.counters->nsteals, (unsigned long long)w_steals);
+    if (w_steal_refused) atomicAdd(&a.counters->steal_refused, (unsigned long long)w_steal_refused);
     if (w_collide_passes) {
       atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
     }
@@ -1429,32 +1331,20 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
           k.steal_min = atoi(force);
         }
       }
-      if (a.queue && k.steal_min > 0) {
-        /* the CU lists of the collision stage's waves start empty (g_cu_count / g_cu_members) */
-        static void* cu_count = nullptr;
-        static void* cu_members = nullptr;
-        static void* ring_readers = nullptr;
-        static void* xcd_count = nullptr;
-        static void* xcd_members = nullptr;
-        if (!cu_count) {
-          (void)hipGetSymbolAddress(&cu_count, HIP_SYMBOL(g_cu_count));
-          (void)hipGetSymbolAddress(&cu_members, HIP_SYMBOL(g_cu_members));
-          (void)hipGetSymbolAddress(&ring_readers, HIP_SYMBOL(g_ring_readers));
-          (void)hipGetSymbolAddress(&xcd_count, HIP_SYMBOL(g_xcd_count));
-          (void)hipGetSymbolAddress(&xcd_members, HIP_SYMBOL(g_xcd_members));
+      k.steal_delay = 0;
+      {
+        const char* delay = getenv("NEUTRAL_STEAL_DELAY"); /* (tests: a slow thief) */
+        if (delay && atoi(delay) > 0) {
+          k.steal_delay = atoi(delay);
         }
-        if (cu_count && cu_members && ring_readers && xcd_count && xcd_members &&
-            hipMemsetAsync(xcd_count, 0, sizeof(unsigned) * kXcdSlots, stream) == hipSuccess &&
-            hipMemsetAsync(xcd_members, 0xFF, sizeof(unsigned) * kXcdSlots * kXcdWavesMax, stream) ==
-                hipSuccess &&
-            hipMemsetAsync(cu_count, 0, sizeof(unsigned) * kCuSlots, stream) == hipSuccess &&
-            hipMemsetAsync(cu_members, 0xFF, sizeof(unsigned) * kCuSlots * kCuWavesMax, stream) ==
-                hipSuccess &&
-            hipMemsetAsync(ring_readers, 0, sizeof(unsigned) * kRingCtlSlots, stream) == hipSuccess) {
-          /* (lists empty, every entry invalid) */
-        } else {
-          k.steal_min = 0; /* no lists, no stealing: a stale list could name a wave of another CU */
-        }
+      }
+      if (a.queue && k.steal) {
+        /* rings' control words zero, CU lists empty (every entry invalid), nobody reading */
+        hipLaunchKernelGGL(steal_reset_kernel, dim3((kCuSlots * kCuWavesMax + 255) / 256), dim3(256), 0,
+                           stream, k.steal);
+      } else {
+        k.steal = nullptr; /* (no workspace: equal shares without rings, first-come queue) */
+        k.steal_min = 0;
       }
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, stream, k);
     };

@@ -59,10 +59,7 @@ namespace neutral {
 
 constexpr int kWindow = kWindowCells; /* cells per LDS window edge (neutral_history.h; 88 and
                                          two windows when the scalar flux is kept) */
-#ifndef NEUTRAL_STREAM_BLOCK
-#define NEUTRAL_STREAM_BLOCK 1024
-#endif
-constexpr int kStreamBlock = NEUTRAL_STREAM_BLOCK; /* 16 waves share one window */
+constexpr int kStreamBlock = 1024; /* 16 waves share one window */
 /* A chunk is what one workgroup takes at a time from one tile's particles: big
  * enough to amortise its two barriers and a window move, small enough that
  * every workgroup gets several (the host picks the size from the particle
@@ -73,28 +70,15 @@ constexpr int kChunkParticlesMax = 32768;
  * few thousand puts a whole tile, four histories per lane one after the other, on ONE
  * workgroup: stream 4000^2 / 1e6 64.9 -> 53.9 ms, profiles/r03/sparse_knobs.log) */
 constexpr int kChunkParticlesMin = 1024;
-constexpr int kChunkParticlesFloor = 512; /* (what NEUTRAL_CHUNK_MIN may go down to) */
 /* empty lanes that trigger a refill.  With the facet loop as lean as it is now a
  * wave does best refilling (almost) as a whole: its particles come from one tile and
  * start together, so their loads and LDS atomics stay close, which is worth more than
  * the idle lanes of the last facets (56: stream deck -6 %, csp -2 % against 32;
  * 56...64 are level) */
-#ifndef NEUTRAL_STREAM_REFILL_MIN
-#define NEUTRAL_STREAM_REFILL_MIN 56
-#endif
-constexpr int kStreamRefillMin = NEUTRAL_STREAM_REFILL_MIN;
+constexpr int kStreamRefillMin = 56;
 /* facet crossings per STREAM pass (64: a csp history's whole flight of ~63 facets;
  * -1..2 % against 16) */
-#ifndef NEUTRAL_STREAM_REPEAT
-#define NEUTRAL_STREAM_REPEAT 64
-#endif
-constexpr int kStreamRepeat = NEUTRAL_STREAM_REPEAT;
-/* (experiment switch: NEUTRAL_NO_CARRIED_TARGETS reads all four edges at every loop head) */
-#if defined(NEUTRAL_NO_CARRIED_TARGETS)
-constexpr bool kCarryTargets = false;
-#else
-constexpr bool kCarryTargets = true;
-#endif
+constexpr int kStreamRepeat = 64;
 constexpr int kSortBlock = 256;
 /* counting sort: records one workgroup histograms and places at a time, and the
  * largest number of buckets (tiles + 1) it keeps in LDS (count + base: 64 KB);
@@ -114,23 +98,34 @@ enum Ctrl : int {
   kCtrlEmigrants = 7,  /* decomposed mesh: histories waiting to be sent to another rank */
   kCtrlFirstInactive = 8, /* first slot of the particles that were dead when the step began
                              (pass 0 carries them over behind the live ones) */
+  kCtrlLive = 9,       /* histories of this launch of the stream kernel that have not ended in
+                          it yet (its workgroups leave when it is zero) */
+  kCtrlHops = 10,      /* histories handed to another tile's queue inside the stream kernel */
+  kCtrlOverflows = 11, /* ... that found the queue full and wait for the next pass instead */
+  kCtrlBatches = 12,   /* claims of a workgroup on a tile's queue */
+  kCtrlIdlePolls = 13, /* sweeps of a workgroup that found nothing to take */
 };
+/* ---- the asynchronous tile queue (TiledArgs::queue_entries) ---- */
+constexpr unsigned kQueueEmpty = 0xFFFFFFFFu; /* a place that is reserved but not written yet */
+/* a workgroup prefers a queue over a fresh chunk from this many waiting histories on (one per
+ * lane): migrants are worked off while the tiles they came from are still being streamed,
+ * instead of piling up for a pass of their own */
+constexpr unsigned kQueueBatchMin = 1024;
+constexpr unsigned kQueueBatchMax = 4096; /* histories a workgroup claims at a time */
+/* polls of a workgroup that finds nothing to do while histories are still in flight elsewhere
+ * (each a sweep over the tiles' counters and a sleep: several microseconds) before it gives up
+ * and reports the launch as aborted -- seconds; a launch lasts milliseconds */
+constexpr unsigned kQueueIdlePollsMax = 1u << 20;
 /* A history of a chunk WITHOUT a window (a sparse tile, the small tail of a dense one)
  * runs on global atomics.  When other chunks of the pass do have windows it is handed
  * to the next pass after this many facet crossings (about one window's worth), like a
  * history that left its window: the next sort may put it into a tile that is worth a
  * window, and no pass has to wait for a lone history that crosses thousands of cells
  * (the reference's stream deck as shipped: 7 000 facets per history and step). */
-#ifndef NEUTRAL_UNWINDOWED_BUDGET
-#define NEUTRAL_UNWINDOWED_BUDGET 160
-#endif
-constexpr unsigned kUnwindowedBudget = NEUTRAL_UNWINDOWED_BUDGET;
+constexpr unsigned kUnwindowedBudget = 160;
 /* a history leaves its window for another pass only if about this many facet
  * crossings still lie ahead; shorter tails finish with global atomics */
-#ifndef NEUTRAL_MIGRATE_MIN_FACETS
-#define NEUTRAL_MIGRATE_MIN_FACETS 8.0
-#endif
-constexpr double kMigrateMinFacets = NEUTRAL_MIGRATE_MIN_FACETS;
+constexpr double kMigrateMinFacets = 8.0;
 constexpr int kMaxStreamPasses = 256;
 
 /* ---- 1. counting sort of the live records by tile ----------------------------------- */
@@ -145,9 +140,9 @@ __device__ __forceinline__ unsigned sort_bucket(const TiledArgs& t, unsigned sum
   const int state = summary_state(summary);
   /* (tile, reach class): the classes of a tile follow each other, shortest flights first) */
   /* (longest flights first: the chunks of a tile are handed out in this order, and the
-   * long ones are the ones worth starting early -- stream 4000^2 / 1e6 49.5 -> 47.9 ms;
-   * NEUTRAL_REACH_SHORTEST_FIRST is the A/B) */
-  const unsigned cls = t.reach_longest_first ? 3u - summary_reach(summary) : summary_reach(summary);
+   * long ones are the ones worth starting early -- stream 4000^2 / 1e6 49.5 -> 47.9 ms,
+   * profiles/r03/experiments/reach_class_ab.log) */
+  const unsigned cls = 3u - summary_reach(summary);
   const unsigned live = (t.reach_classes > 1)
                             ? summary_tile(summary) * (unsigned)t.reach_classes + cls
                             : summary_tile(summary);
@@ -168,12 +163,17 @@ __device__ __forceinline__ const unsigned* sort_summaries(const TiledArgs& t) {
 __device__ __forceinline__ bool pass_is_empty(const TiledArgs& t) {
   return t.pass > 0 && t.ctrl[kCtrlMigrants] == 0;
 }
+/* an earlier launch of this step dropped histories (a defect the host reports: their summaries
+ * were never written): nothing more of the step runs on what it left behind */
+__device__ __forceinline__ bool step_is_broken(const SolveArgs& a) {
+  return a.counters->aborted != 0u;
+}
 
 /* histogram: tile_count[b] += records of bucket b (tile_count is zero on entry:
  * tile_scan_kernel clears what it has consumed) */
 __global__ __launch_bounds__(kSortBlock) void tile_count_kernel(SolveArgs a, TiledArgs t) {
   extern __shared__ unsigned s_bins[];
-  if (pass_is_empty(t)) {
+  if (pass_is_empty(t) || (t.pass > 0 && step_is_broken(a))) {
     return;
   }
   const int nbins = t.nsort + 1;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
  * sum.) */
 __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, TiledArgs t) {
   extern __shared__ unsigned s_bins[]; /* count/rank [nbins], base [nbins] */
-  if (pass_is_empty(t)) {
+  if (pass_is_empty(t) || (t.pass > 0 && step_is_broken(a))) {
     return;
   }
   const int nbins = t.nsort + 1;
@@ -370,6 +370,9 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
    * suspended (scatter 1e8: one per 256 records cost 3.9 ms of atomics) */
   __shared__ unsigned s_count[kSortItems][kSortBlock / 64];
   __shared__ unsigned s_base;
+  if (step_is_broken(a)) {
+    return;
+  }
   const long long base = (long long)blockIdx.x * kSortSegment;
   const int wave = threadIdx.x >> 6;
   unsigned mine = 0; /* bit k: record base + k * kSortBlock + threadIdx.x is suspended */
@@ -443,30 +446,21 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
  * id instead costs one scattered 4-B write per particle (slot_of_id, by the kernel that
  * places the record: pass 0 of the stream kernel, copy_inactive, the import), one
  * random 80-B record read, and eleven fully coalesced stores. */
-__global__ __launch_bounds__(kSortBlock) void invert_ids_kernel(const ParticleRec* rec,
-                                                                unsigned* slot_of_id, int n) {
-  const int i = blockIdx.x * kSortBlock + threadIdx.x;
-  if (i < n) {
-    const unsigned id = rec[i].id; /* (a 64-B sector for 4 bytes: only where somebody asks
-                                      for the arrays after steps in lazy mode) */
-    if (id < (unsigned)n) {
-      slot_of_id[id] = (unsigned)i;
-    }
-  }
-}
-
 __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const ParticleRec* rec,
                                                                     const unsigned* slot_of_id,
                                                                     ParticleView p, int n,
                                                                     const int* abort_flag,
-                                                                    const unsigned* first_inactive) {
+                                                                    const unsigned* first_inactive,
+                                                                    unsigned final_from) {
   if (abort_flag && *abort_flag) {
     return; /* the step's kernels have done nothing: rec holds an older step */
   }
   const int k = blockIdx.x * kSortBlock + threadIdx.x;
   if (k < n) {
     const unsigned slot = slot_of_id[k];
-    if (first_inactive && slot >= *first_inactive) {
+    /* (the boundary as the step's sort found it, on the device -- or, written back on demand,
+     * as the host remembers it from when the arrays were last current) */
+    if (slot >= (first_inactive ? *first_inactive : final_from)) {
       return; /* dead since before the step began: the arrays have its final state, and the
                  random access to its record -- what this pass is bound by -- is saved */
     }
@@ -598,6 +592,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(TiledArgs t) {
   if (tid == 1023) {
     t.ctrl[kCtrlNumChunks] = s_chunks[1023];
     t.ctrl[kCtrlActive] = nactive;
+    t.ctrl[kCtrlLive] = nactive; /* (every one of them ends in this launch, or waits in a queue of it) */
     t.ctrl[kCtrlChunkHead] = 0;
     t.ctrl[kCtrlCollideCount] = 0;
     t.ctrl[kCtrlMigrants] = 0;
@@ -679,6 +674,24 @@ __global__ __launch_bounds__(1024) void edges_check_kernel(SolveArgs a, TiledArg
 
 /* ---- 2. streaming kernel with the LDS tally window ------------------------------ */
 
+/* One workgroup per tile, ahead of every launch of the stream kernel: the places of the tile's
+ * log that the last launch used are empty again, the log starts over.  (A launch that handed
+ * nobody on -- most launches after the first of a step -- leaves nothing to clear.) */
+__global__ __launch_bounds__(kSortBlock) void queue_reset_kernel(TiledArgs t) {
+  const int tile = (int)blockIdx.x;
+  unsigned used = t.queue_tail[tile];
+  used = (used > t.queue_capacity) ? t.queue_capacity : used;
+  unsigned* log = t.queue_entries + (size_t)tile * t.queue_capacity;
+  for (unsigned i = threadIdx.x; i < used; i += kSortBlock) {
+    log[i] = kQueueEmpty;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    t.queue_tail[tile] = 0u;
+    t.queue_head[tile] = 0u;
+  }
+}
+
 template <int kW>
 __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window, double* mesh,
                                              int ox, int oy) {
@@ -709,7 +722,7 @@ __host__ __device__ __forceinline__ size_t stream_lds_payload_bytes(const SolveA
   }
   return (lds + 15) & ~(size_t)15;
 }
-constexpr size_t kStreamLdsControlBytes = 32;
+constexpr size_t kStreamLdsControlBytes = 64;
 
 /* more than kMigrateMinFacets facets ahead of it before the census, at the rate its
  * direction crosses cells? */
@@ -737,6 +750,9 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   int& s_tile = lds_ctl[2];
   int& s_windowed = lds_ctl[3];
   int& s_cursor = lds_ctl[4];
+  int& s_kind = lds_ctl[5];                      /* kWorkChunk / kWorkQueue / kWorkNone */
+  unsigned& s_best = ((unsigned*)lds_ctl)[6];    /* the sweep over the tile queues: fullest ... */
+  int& s_best_tile = lds_ctl[7];                 /* ... and which */
 
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
@@ -766,10 +782,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   const int nchunks = (int)t.ctrl[kCtrlNumChunks];
   /* do SolveArgs::edge_dx / edge_dy reproduce the edge arrays this step?  (wave-uniform) */
   const bool edges_computed =
-      kCarryTargets && t.edges_computed && __builtin_amdgcn_readfirstlane(*t.edges_computed) != 0;
+      t.edges_computed && __builtin_amdgcn_readfirstlane(*t.edges_computed) != 0;
   /* histories without a window move on after a window's worth of facets when the
    * pass has windows to offer (wave-uniform) */
-  const bool budget_on = t.allow_migrate && t.ctrl[kCtrlWindowed] != 0;
+  const bool budget_on = t.allow_migrate && (t.queue_entries != nullptr || t.ctrl[kCtrlWindowed] != 0);
   int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
   int win_ox = 0;
   int win_oy = 0;
@@ -785,26 +801,147 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   h.ev = kEvEnd;
   int pid = -1;
 
+  /* the tile queues are in use (wave-uniform): migrants change tiles inside this launch */
+  const bool queues = t.queue_entries != nullptr && t.allow_migrate;
+  const unsigned qcap = t.queue_capacity;
+  unsigned w_ended = 0;     /* histories this wave has ended for this launch since its last report */
+  unsigned w_hops = 0;
+  unsigned w_overflows = 0;
+  unsigned wg_batches = 0;    /* (thread 0's: NeutralHipStepStats.stream_batches / stream_idle_polls) */
+  unsigned wg_idle_polls = 0;
+  enum : int { kWorkChunk = 0, kWorkQueue = 1, kWorkNone = 2 };
+
   for (;;) {
-    __syncthreads(); /* the previous chunk is complete (also orders the staging above) */
-    if (threadIdx.x == 0) {
-      const int c = (int)atomicAdd(&t.ctrl[kCtrlChunkHead], 1u);
-      s_chunk = c;
-      if (c < nchunks) {
-        const uint4 ch = t.chunks[c];
-        s_cursor = (int)ch.x;
-        s_end = (int)ch.y;
-        s_tile = (int)ch.z;
-        s_windowed = (int)ch.w;
-      }
+    if (queues && (threadIdx.x & 63) == 0 && w_ended) {
+      atomicSub(&t.ctrl[kCtrlLive], w_ended);
     }
-    __syncthreads();
+    w_ended = 0;
+    /* ---- what next?  A queue with a workgroup's worth of waiting histories, else a fresh
+     * chunk, else whatever waits in any queue; with nothing to take and histories still in
+     * flight elsewhere (they may yet arrive here): look again; with none: done. ---- */
+    unsigned polls = 0;
+    for (;;) {
+      __syncthreads(); /* the previous work is complete (also orders the staging above) */
+      if (threadIdx.x == 0) {
+        s_best = 0u;
+        s_best_tile = -1;
+        s_kind = kWorkNone;
+      }
+      __syncthreads();
+      if (queues) {
+        /* sweep: the fullest queue (ties and near-ties broken differently by every workgroup
+         * and poll, so that workgroups looking at the same moment spread over the tiles) */
+        unsigned mine = 0u;
+        int mine_tile = -1;
+        for (int tile = (int)threadIdx.x; tile < t.ntiles; tile += kStreamBlock) {
+          unsigned tail = __hip_atomic_load(&t.queue_tail[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned head = __hip_atomic_load(&t.queue_head[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tail = (tail > qcap) ? qcap : tail;
+          if (tail > head) {
+            unsigned waiting = tail - head;
+            waiting = (waiting > 0xFFFFFu) ? 0xFFFFFu : waiting;
+            const unsigned salt = ((unsigned)tile * 2654435761u + blockIdx.x * 40503u + polls * 9973u) >> 20;
+            const unsigned key = (waiting << 12) | salt;
+            if (key > mine) {
+              mine = key;
+              mine_tile = tile;
+            }
+          }
+        }
+        unsigned most = mine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned other = __shfl_xor(most, off, 64);
+          most = (other > most) ? other : most;
+        }
+        const unsigned long long m_top = __ballot(most != 0u && mine == most);
+        if (m_top != 0ull && __builtin_ctzll(m_top) == (int)(threadIdx.x & 63)) {
+          atomicMax(&s_best, most);
+        }
+        __syncthreads();
+        if (mine != 0u && mine == s_best) {
+          s_best_tile = mine_tile; /* (equal keys: equally full, either will do) */
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        const unsigned waiting = queues ? (s_best >> 12) : 0u;
+        int kind = kWorkNone;
+        /* a claim on a tile's queue: places [head, head + m) of its log */
+        auto claim = [&](int tile) -> bool {
+          for (;;) {
+            const unsigned head = __hip_atomic_load(&t.queue_head[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned tail = __hip_atomic_load(&t.queue_tail[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail = (tail > qcap) ? qcap : tail;
+            if (tail <= head) {
+              return false; /* (others were quicker) */
+            }
+            unsigned m = tail - head;
+            m = (m > kQueueBatchMax) ? kQueueBatchMax : m;
+            if (atomicCAS(&t.queue_head[tile], head, head + m) == head) {
+              s_cursor = (int)head;
+              s_end = (int)(head + m);
+              s_tile = tile;
+              s_windowed = 1;
+              return true;
+            }
+          }
+        };
+        if (waiting >= kQueueBatchMin && claim(s_best_tile)) {
+          kind = kWorkQueue;
+        }
+        if (kind == kWorkNone &&
+            __hip_atomic_load(&t.ctrl[kCtrlChunkHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks) {
+          const int c = (int)atomicAdd(&t.ctrl[kCtrlChunkHead], 1u);
+          if (c < nchunks) {
+            const uint4 ch = t.chunks[c];
+            s_cursor = (int)ch.x;
+            s_end = (int)ch.y;
+            s_tile = (int)ch.z;
+            s_windowed = (int)ch.w;
+            kind = kWorkChunk;
+          }
+        }
+        if (kind == kWorkNone && waiting > 0u && claim(s_best_tile)) {
+          kind = kWorkQueue;
+        }
+        s_kind = kind;
+        if (kind == kWorkQueue) {
+          wg_batches++;
+        } else if (kind == kWorkNone) {
+          wg_idle_polls++;
+        }
+        /* nothing to take: is anything still in flight?  (s_chunk < 0: the workgroup leaves) */
+        s_chunk = 0;
+        if (kind == kWorkNone) {
+          const unsigned live = queues ? __hip_atomic_load(&t.ctrl[kCtrlLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+          if (live == 0u || waiting > 0u) {
+            s_chunk = (live == 0u) ? -1 : 0; /* (a queue had something a moment ago: look again at once) */
+          } else if (polls >= kQueueIdlePollsMax) {
+            atomicAdd(&a.counters->aborted, 1u); /* (histories in flight that never arrive: a defect) */
+            s_chunk = -1;
+          } else {
+            __builtin_amdgcn_s_sleep(32);
+          }
+        }
+      }
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(s_kind) != kWorkNone || __builtin_amdgcn_readfirstlane(s_chunk) < 0) {
+        break;
+      }
+      polls++;
+    }
     /* (values read from LDS arrive in vector registers: readfirstlane tells the
      * compiler they are wave-uniform, so the chunk bookkeeping and the window
      * origin stay on the scalar unit) */
-    if (__builtin_amdgcn_readfirstlane(s_chunk) >= nchunks) {
+    const int work = __builtin_amdgcn_readfirstlane(s_kind);
+    if (work == kWorkNone) {
       break;
     }
+    const bool from_queue = (work == kWorkQueue);
+    /* a fresh history (pass 0, from the sorted order): prologue, its place in rec_out is its
+     * position; anything else resumes in place */
+    const bool fresh = !from_queue && t.pass == 0;
     const int chunk_end = __builtin_amdgcn_readfirstlane(s_end);
     const int chunk_tile = __builtin_amdgcn_readfirstlane(s_tile);
     /* a dense tile's chunk (tile_chunks_kernel) */
@@ -844,6 +981,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       int park = kRecIdle; /* kRecCollide / kRecMigrate: this lane hands its history on */
       bool did_census = false;
+      bool ended = false; /* this lane's history is over as far as this launch is concerned */
       if (n_empty >= t.refill_min || n_stream == 0) {
         /* REFILL: take n_empty ids of the chunk */
         int base = 0;
@@ -856,17 +994,47 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         } else {
           const int mine = base + lane_rank(m_empty);
           /* wave-level bookkeeping (scalar registers, not one VGPR per counter) */
-          if (t.pass == 0) {
+          if (fresh) {
             const int left = chunk_end - base;
             w_processed += (unsigned)((n_empty < left) ? n_empty : left);
           }
           if (!has && mine < chunk_end) {
             /* pass 0 reads last step's records through the sorted order and writes
              * this step's in tile order; later passes work on their migrants in place */
-            const unsigned src = t.order[mine];
-            pid = (t.pass == 0) ? mine : (int)src; /* this history's slot in rec_out */
-            load_record(h, a, (t.pass == 0) ? t.rec_in[src] : t.rec_out[src]);
-            if (t.pass == 0) {
+            unsigned src;
+            if (from_queue) {
+              /* place `mine` of the tile's log: reserved before it was claimed, written a
+               * moment after it was reserved (bounded wait: a place never written is a defect,
+               * and its history is reported, not waited for) */
+              const unsigned* place = t.queue_entries + ((size_t)chunk_tile * qcap + (size_t)mine);
+              unsigned spins = 0;
+              do {
+                src = __hip_atomic_load(place, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } while (src == kQueueEmpty && ++spins < (1u << 22));
+            } else {
+              src = t.order[mine];
+            }
+            /* (a slot number that is none -- a place never written, or anything else that is not
+             * a record of this store -- is reported and dropped, never dereferenced) */
+            if (src >= (unsigned)a.nparticles) {
+              atomicAdd(&a.counters->aborted, 1u);
+            } else {
+            pid = fresh ? mine : (int)src; /* this history's slot in rec_out */
+            bool bad_load = false;
+            if (from_queue || (queues && !fresh)) {
+              /* stored by another workgroup of this launch: around the L1 (neutral_history.h);
+               * (a later pass's own migrants too: its lines' neighbours are changing hands) */
+              load_record_through(h, a, t.rec_out[src]);
+              if (from_queue) {
+                const int want_tile = ((h.celly - a.y_off) >> t.tile_shift) * t.tiles_x + ((h.cellx - a.x_off) >> t.tile_shift);
+                /* (a record that does not belong to the queue it was taken from is a defect of
+                 * the hand-off: reported and dropped, never streamed) */
+                bad_load = (want_tile != chunk_tile) | (!kDomain && h.id >= (unsigned)a.nparticles);
+              }
+            } else {
+              load_record(h, a, fresh ? t.rec_in[src] : t.rec_out[src]);
+            }
+            if (fresh) {
               /* who lives in the slot / where the particle lives: what the write-back (or a
                * decomposed store's compaction) goes by, without reading 80-B records */
               if (kDomain) {
@@ -875,7 +1043,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                 t.slot_of_id[h.id] = (unsigned)pid;
               }
             }
-            if (t.pass == 0) {
+            if (bad_load) {
+              atomicAdd(&a.counters->aborted, 1u);
+            } else {
+            if (fresh) {
               prologue<kSameTables, kChecked>(h, a, ix);
             } else {
               resume<kSameTables, kChecked>(h, a, ix); /* a migrant: mid-history, no draw pending */
@@ -889,21 +1060,19 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             h.plain_div = 0;
             refresh_speed_reciprocal<kChecked>(h); /* no collision here: the speed stays */
             refresh_mfp_reciprocal<kChecked>(h);
-            if (kCarryTargets) {
-              /* (wave-uniform branch: computed or loaded, the same bits) */
-              if (edges_computed) {
-                load_targets<true>(h, a);
-              } else {
-                load_targets<false>(h, a);
-              }
-              decide_carried(h);
-              h.nevents++; /* (as decide() counts it) */
+            /* (wave-uniform branch: computed or loaded, the same bits) */
+            if (edges_computed) {
+              load_targets<true>(h, a);
             } else {
-              decide(h, a);
+              load_targets<false>(h, a);
             }
+            decide_carried(h);
+            h.nevents++; /* (as decide() counts it) */
             has = true;
             if (h.ev == kEvCollision) {
               park = kRecCollide;
+            }
+            }
             }
           }
         }
@@ -926,108 +1095,54 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
-          if (kCarryTargets) {
-            /* One exit, at the bottom.  "Outside the window with a long way to go: continue in
-             * the pass that centres a window on wherever the particle is by then" is asked
-             * about the cell a crossing ENTERS, together with "is the next event another
-             * facet" -- before the first trip for the cell the history starts in -- so a trip
-             * has one place where lanes leave, and the window coordinates of the new cell are
-             * worked out once: for that question and for the next trip's tally. */
-            WindowCellTallyT<kFlux, kUniform> cell_tally{
-                tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
-                (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
-            bool out_of_window = cell_tally.outside();
-            cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
-            bool run = true;
-            if ((cell_tally.m_outside & may_migrate) != 0) {
-              asm volatile(""); /* (a branch the wave takes or skips, not a predicated block) */
-              if (out_of_window) {
-                run = !far_to_go(h, t);
-              }
+          /* One exit, at the bottom.  "Outside the window with a long way to go: continue in
+           * the pass that centres a window on wherever the particle is by then" is asked
+           * about the cell a crossing ENTERS, together with "is the next event another
+           * facet" -- before the first trip for the cell the history starts in -- so a trip
+           * has one place where lanes leave, and the window coordinates of the new cell are
+           * worked out once: for that question and for the next trip's tally. */
+          WindowCellTallyT<kFlux, kUniform> cell_tally{
+              tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
+              (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
+          bool out_of_window = cell_tally.outside();
+          cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
+          bool run = true;
+          if ((cell_tally.m_outside & may_migrate) != 0) {
+            asm volatile(""); /* (a branch the wave takes or skips, not a predicated block) */
+            if (out_of_window) {
+              run = !far_to_go(h, t);
             }
-            if (run) {
-#pragma unroll 1
-              do {
-                /* (tallies the cell it leaves: this one) */
-                cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
-                /* (counted in place, by hand: written as ++crossed the compiler compares the
-                 * old value, adds into a new register and copies it back) */
-                asm("v_add_u32_e32 %0, 1, %0" : "+v"(crossed));
-                if (kDomain) {
-                  /* the neighbour cell may belong to another rank: the history stops on the
-                   * facet, before anything of that cell (edges, density) is looked at */
-                  if (outside_domain(h, a)) {
-                    park = kRecEmigrate;
-                    break;
-                  }
-                }
-                cell_tally.lx = (unsigned)(h.cellx - a.x_off - tally.ox);
-                cell_tally.ly = (unsigned)(h.celly - a.y_off - tally.oy);
-                out_of_window = cell_tally.outside();
-                cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
-                /* (what ends the flight is named below the loop, once; `crossed` is the trip
-                 * count too: every lane in the loop started with it) */
-                run = next_is_facet(h) & (crossed < kStreamRepeat);
-                if ((cell_tally.m_outside & may_migrate) != 0) {
-                  asm volatile("");
-                  if (out_of_window) {
-                    run = run & !far_to_go(h, t);
-                  }
-                }
-              } while (run);
-            }
-            return;
           }
-          /* (the experiment build without carried targets, NEUTRAL_NO_CARRIED_TARGETS: the
-           * loop as it was, with its two exits) */
+          if (run) {
 #pragma unroll 1
-          for (;;) {
-            /* outside the window with a long way to go: continue in the pass that
-             * centres a window on wherever the particle is by then */
-            bool leave = false;
-            WindowCellTallyT<kFlux, kUniform> cell_tally{
-                tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
-                (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
-            const bool out_of_window = cell_tally.outside();
-            cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
-            /* (wave-uniform test first: most trips have every lane inside the window, and
-             * the four operations below issue whether a lane wants them or not) */
-            if ((cell_tally.m_outside & may_migrate) != 0) {
-              asm volatile(""); /* (keeps this a branch the wave takes or skips) */
-              if (out_of_window) {
-                leave = far_to_go(h, t);
+            do {
+              /* (tallies the cell it leaves: this one) */
+              cross_facet<kChecked, true, kDomain ? 1 : 0, true, kEdges>(h, a, cell_tally);
+              /* (counted in place, by hand: written as ++crossed the compiler compares the
+               * old value, adds into a new register and copies it back) */
+              asm("v_add_u32_e32 %0, 1, %0" : "+v"(crossed));
+              if (kDomain) {
+                /* the neighbour cell may belong to another rank: the history stops on the
+                 * facet, before anything of that cell (edges, density) is looked at */
+                if (outside_domain(h, a)) {
+                  park = kRecEmigrate;
+                  break;
+                }
               }
-            }
-            if (leave) {
-              break; /* (why is worked out again below, once: nothing per trip records it) */
-            }
-            /* (tallies the cell it leaves: this one) */
-            cross_facet<kChecked, true, kDomain ? 1 : 0, kCarryTargets, kEdges>(h, a, cell_tally);
-            /* (counted in place, by hand: written as ++crossed the compiler compares the old
-             * value, adds into a new register and copies it back -- three instructions) */
-            asm("v_add_u32_e32 %0, 1, %0" : "+v"(crossed));
-            if (kDomain) {
-              /* the neighbour cell may belong to another rank: the history stops on the
-               * facet, before anything of that cell (edges, density) is looked at */
-              if (outside_domain(h, a)) {
-                park = kRecEmigrate;
-                break;
+              cell_tally.lx = (unsigned)(h.cellx - a.x_off - tally.ox);
+              cell_tally.ly = (unsigned)(h.celly - a.y_off - tally.oy);
+              out_of_window = cell_tally.outside();
+              cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
+              /* (what ends the flight is named below the loop, once; `crossed` is the trip
+               * count too: every lane in the loop started with it) */
+              run = next_is_facet(h) & (crossed < kStreamRepeat);
+              if ((cell_tally.m_outside & may_migrate) != 0) {
+                asm volatile("");
+                if (out_of_window) {
+                  run = run & !far_to_go(h, t);
+                }
               }
-            }
-            /* (selects, then one exit test: the nested form costs ~15 more scalar
-             * exec-mask instructions per facet) */
-            bool goes_on;
-            if (kCarryTargets) {
-              goes_on = next_is_facet(h); /* (what ends the flight is named below, once) */
-            } else {
-              decide<false>(h, a);
-              goes_on = (h.ev == kEvFacet);
-              park = (h.ev == kEvCollision) ? (int)kRecCollide : park;
-            }
-            /* (`crossed` is the trip count too: every lane in the loop started with it) */
-            if (!goes_on | (crossed >= kStreamRepeat)) {
-              break;
-            }
+            } while (run);
           }
           };
           /* ... and for a mesh whose edges the device has found to follow the host layer's
@@ -1045,12 +1160,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               run_facets(std::false_type{}, std::false_type{});
             }
           }
-          if (kCarryTargets) {
-            /* the event that ended the run of crossings (or another facet), from the
-             * state the loop left: the comparisons next_is_facet() made, with names */
-            decide_carried(h);
-            park = (park == kRecIdle && h.ev == kEvCollision) ? (int)kRecCollide : park;
-          }
+          /* the event that ended the run of crossings (or another facet), from the
+           * state the loop left: the comparisons next_is_facet() made, with names */
+          decide_carried(h);
+          park = (park == kRecIdle && h.ev == kEvCollision) ? (int)kRecCollide : park;
           /* a history that stopped in front of a facet, outside the window and with far to
            * go, moves on to the pass that centres a window on it: the one that left the loop
            * for that reason, and the one the loop's trip count stopped (it would leave on
@@ -1085,7 +1198,16 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             census<kChecked>(h, a, tally);
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
-          store_record(h, a, t.rec_out[pid], kRecIdle);
+          /* (with the tile queues in use EVERY record of this launch is stored write-through and
+           * read around the L1: one protocol for every access to an array whose 128-byte lines
+           * are shared by records that change hands.  tools/micro/handoff_litmus.hip measures
+           * that protocol; its variant 4 -- a plain last store -- showed no stale read either,
+           * but a plain store leaves a dirty line in this XCD's L2 that nothing here needs) */
+          if (queues) {
+            store_record_through(h, a, t.rec_out[pid], kRecIdle);
+          } else {
+            store_record(h, a, t.rec_out[pid], kRecIdle);
+          }
           /* (its reach class: where the next step's pass 0 puts it inside its tile) */
           t.info_out[pid] = slot_summary(
               kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
@@ -1093,20 +1215,72 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                                                 h.celly - a.y_off, t.tile_shift, kW, t.cells_per_x,
                                                 t.cells_per_y)
                                   : 0u);
-          if (a.export_view) {
-            /* the interface's arrays stay current (pointers fetched here, not kept
-             * in registers through the facet loop) */
-            const ParticleView* pv = a.export_view;
-            asm volatile("" : "+s"(pv));
-            store_particle_view(h, *pv, (int)h.id);
-          }
           has = false;
+          ended = true;
           did_census = (h.ev == kEvCensus);
         }
       }
-      /* histories handed on: the record carries the state; migrants are counted */
-      if (park != kRecIdle) {
-        store_record(h, a, t.rec_out[pid], park);
+      /* ---- histories handed on: the record carries the state ---- */
+      /* A migrant goes to the queue of the tile it has reached, to be streamed on under a
+       * window centred there by whichever workgroup claims it, inside this launch: the record
+       * is stored write-through, the wave waits for its stores, reserves places in the tiles'
+       * logs -- one atomic per tile the wave's migrants go to, all of them in one instruction
+       * -- and writes the slots there (neutral_history.h: records that change hands inside a
+       * launch).  A log that is full sends its migrant to the next pass instead. */
+      bool queued = false;
+      const bool hop = queues && park == kRecMigrate;
+      const unsigned long long m_hop = __ballot(hop);
+      if (m_hop != 0ull) { /* (wave-uniform) */
+        int dest = 0;
+        if (hop) {
+          dest = ((h.celly - a.y_off) >> t.tile_shift) * t.tiles_x + ((h.cellx - a.x_off) >> t.tile_shift);
+          if ((unsigned)dest >= (unsigned)t.ntiles || (unsigned)pid >= (unsigned)a.nparticles) {
+            atomicAdd(&a.counters->aborted, 1u); /* (a cell outside the mesh: reported, never indexed with) */
+            dest = 0;
+          }
+          store_record_through(h, a, t.rec_out[(unsigned)pid < (unsigned)a.nparticles ? pid : 0], kRecMigrate);
+        }
+        /* lanes bound for the same tile: the first of them reserves for all */
+        int leader = -1;
+        unsigned rank = 0, group = 0;
+        unsigned long long todo = m_hop;
+        while (todo != 0ull) {
+          const int l = __builtin_ctzll(todo);
+          const int tile_l = __builtin_amdgcn_readlane(dest, l);
+          const unsigned long long same = __ballot(hop && dest == tile_l);
+          if (hop && dest == tile_l) {
+            leader = l;
+            rank = (unsigned)lane_rank(same);
+            group = (unsigned)__popcll(same);
+          }
+          todo &= ~same;
+        }
+        drain_stores(); /* the records are where any workgroup sees them BEFORE their slots are */
+        unsigned base = 0;
+        if (hop && leader == (int)(threadIdx.x & 63)) {
+          base = atomicAdd(&t.queue_tail[dest], group);
+        }
+        base = (unsigned)__shfl((int)base, leader < 0 ? 0 : leader, 64);
+        if (hop) {
+          const unsigned place = base + rank;
+          if (place < qcap) {
+            __hip_atomic_store(t.queue_entries + ((size_t)dest * qcap + (size_t)place), (unsigned)pid,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            queued = true;
+            has = false;
+          }
+        }
+        w_hops += (unsigned)__popcll(__ballot(queued));
+        w_overflows += (unsigned)__popcll(__ballot(hop && !queued));
+      }
+      if (park != kRecIdle && !queued) {
+        if (!hop) { /* (a migrant whose queue was full has its record in place already) */
+          if (queues) {
+            store_record_through(h, a, t.rec_out[pid], park);
+          } else {
+            store_record(h, a, t.rec_out[pid], park);
+          }
+        }
         t.info_out[pid] = slot_summary(
             park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
             (t.reach_classes > 1 && park == kRecMigrate)
@@ -1114,8 +1288,10 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                               t.tile_shift, kW, t.cells_per_x, t.cells_per_y)
                 : 0u);
         has = false;
+        ended = true;
       }
-      w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate));
+      w_ended += (unsigned)__popcll(__ballot(ended));
+      w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate && !queued));
       if (kDomain) {
         w_emigrants += (unsigned)__popcll(__ballot(park == kRecEmigrate));
       }
@@ -1126,6 +1302,18 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
    * word costs more than the streaming itself (one address takes ~100 adds/us) */
   if ((threadIdx.x & 63) == 0 && w_migrants) {
     atomicAdd(&t.ctrl[kCtrlMigrants], w_migrants);
+  }
+  if ((threadIdx.x & 63) == 0 && w_hops) {
+    atomicAdd(&t.ctrl[kCtrlHops], w_hops);
+  }
+  if ((threadIdx.x & 63) == 0 && w_overflows) {
+    atomicAdd(&t.ctrl[kCtrlOverflows], w_overflows);
+  }
+  if (threadIdx.x == 0 && wg_batches) {
+    atomicAdd(&t.ctrl[kCtrlBatches], wg_batches);
+  }
+  if (threadIdx.x == 0 && wg_idle_polls) {
+    atomicAdd(&t.ctrl[kCtrlIdlePolls], wg_idle_polls);
   }
   if (kDomain && (threadIdx.x & 63) == 0 && w_emigrants) {
     atomicAdd(&t.ctrl[kCtrlEmigrants], w_emigrants);
@@ -1369,17 +1557,9 @@ size_t tiled_lds_bytes(const SolveArgs& a) {
 
 int tiled_chunk_particles(int nparticles, int compute_units) {
   /* about six chunks per workgroup when every particle is live */
-#ifndef NEUTRAL_CHUNKS_PER_WG
-#define NEUTRAL_CHUNKS_PER_WG 6
-#endif
-  long long c = (long long)nparticles / ((long long)compute_units * NEUTRAL_CHUNKS_PER_WG);
+  long long c = (long long)nparticles / ((long long)compute_units * 6);
   if (c > kChunkParticlesMax) c = kChunkParticlesMax;
-  int floor_c = kChunkParticlesMin;
-  const char* force = getenv("NEUTRAL_CHUNK_MIN"); /* experiment knob */
-  if (force && atoi(force) >= kChunkParticlesFloor) {
-    floor_c = atoi(force);
-  }
-  if (c < floor_c) c = floor_c;
+  if (c < kChunkParticlesMin) c = kChunkParticlesMin;
   return (int)c;
 }
 
@@ -1427,7 +1607,7 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
   *tiles_x = (nx + tile - 1) / tile;
   *tiles_y = (ny + tile - 1) / tile;
   /* every tile can end with one partial chunk */
-  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesFloor + 1;
+  *max_chunks = (*tiles_x) * (*tiles_y) + nparticles / kChunkParticlesMin + 1;
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
@@ -1443,25 +1623,17 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
 
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream,
-                                 const int* abort_flag, const unsigned* first_inactive) {
+                                 const int* abort_flag, const unsigned* first_inactive,
+                                 unsigned final_from) {
   if (n > 0) {
     const int grid = (n + kSortBlock - 1) / kSortBlock;
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
-                       slot_of_id, p, n, abort_flag, first_inactive);
+                       slot_of_id, p, n, abort_flag, first_inactive, final_from);
   }
   return hipGetLastError();
 }
 
 const unsigned* tiled_first_inactive(const TiledArgs& t) { return &t.ctrl[kCtrlFirstInactive]; }
-
-hipError_t launch_invert_ids(const ParticleRec* rec, unsigned* slot_of_id, int n,
-                             hipStream_t stream) {
-  if (n > 0) {
-    hipLaunchKernelGGL(invert_ids_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
-                       0, stream, rec, slot_of_id, n);
-  }
-  return hipGetLastError();
-}
 
 /* one stream pass: counting sort of the records that take part, chunk list, stream kernel */
 static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass, int cus,
@@ -1484,6 +1656,9 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
     if (after_sort) {
       (void)hipEventRecord(after_sort, stream);
     }
+  }
+  if (t.queue_entries) {
+    hipLaunchKernelGGL(queue_reset_kernel, dim3(t.ntiles), dim3(kSortBlock), 0, stream, t);
   }
   /* one 1024-thread workgroup per CU (the window takes most of the LDS) */
   auto launch = [&](auto kernel) {
@@ -1540,34 +1715,22 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   }
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
-  t.reach_longest_first = getenv("NEUTRAL_REACH_SHORTEST_FIRST") ? 0 : 1; /* (experiment knob) */
   t.refill_min = kStreamRefillMin;
-  {
-    const char* force = getenv("NEUTRAL_STREAM_REFILL"); /* experiment knob */
-    if (force && atoi(force) >= 1 && atoi(force) <= 64) {
-      t.refill_min = atoi(force);
-    }
-  }
   const size_t lds = tiled_lds_bytes(a);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
 
-  static const bool no_uniform = getenv("NEUTRAL_NO_UNIFORM_WINDOWS") != nullptr; /* (A/B knob) */
-  if (no_uniform) {
-    t.tile_uniform = nullptr;
-  }
-  static const bool no_formula = getenv("NEUTRAL_NO_COMPUTED_EDGES") != nullptr; /* (A/B knob) */
   if (first_pass == 0 && t.edges_computed) {
-    if (no_formula) {
-      (void)hipMemsetAsync(t.edges_computed, 0, sizeof(int), stream);
-    } else {
-      hipLaunchKernelGGL(edges_check_kernel, dim3(1), dim3(1024), 0, stream, a, t);
-    }
+    hipLaunchKernelGGL(edges_check_kernel, dim3(1), dim3(1024), 0, stream, a, t);
   }
   if (first_pass == 0 && t.tile_uniform && a.pad == 0) {
     hipLaunchKernelGGL(tile_uniform_kernel, dim3(t.ntiles), dim3(kSortBlock), 0, stream, a, t,
                        a.flux_tally ? kWindowCellsWithFlux : kWindow);
+  } else if (first_pass == 0 && t.tile_uniform) {
+    /* (a padded mesh is not checked: no window of it counts as uniform, whatever an earlier
+     * step of another mesh left in the flags) */
+    (void)hipMemsetAsync(t.tile_uniform, 0, (size_t)t.ntiles, stream);
   }
   /* plan.stream_passes passes, back to back: nothing here waits for the device (the
    * caller reads the migrant counter with the step's counters and comes back for
@@ -1596,14 +1759,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   SolveArgs c = a;
   c.blocks_per_cu = plan.blocks_per_cu;
-  if (!a.export_soa) {
-    c.export_view = nullptr; /* (only the fused experiment stores where a history ends) */
-  }
   {
-    const char* force = getenv("NEUTRAL_K2_BLOCKS_PER_CU"); /* experiment knob */
-    if (force) {
-      c.blocks_per_cu = atoi(force);
-    }
     /* test knob: a small grid makes the collision stage time-slice (shares larger
      * than a wave) at particle counts a CPU oracle can follow */
     const char* max_blocks = getenv("NEUTRAL_K2_MAX_BLOCKS");
@@ -1618,6 +1774,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.tile_shift = t.tile_shift;
   c.susp = t.susp;
   c.susp_track = t.susp_track;
+  c.steal = t.steal;
   c.emigrants = &t.ctrl[kCtrlEmigrants];
   if (t.fine_index && c.same_tables) {
     c.scatter_index = t.fine_index;

@@ -150,6 +150,11 @@ void comms_start_from_env(void) {
     }
     struct timeval tv = {1, 0};
     setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    int rejected = 0;
+    if (!getenv("NEUTRAL_COMM_NONCE")) {
+      fprintf(stderr, "neutral ranks: no NEUTRAL_COMM_NONCE from the launcher: the ranks greet rank 0 "
+                      "with a public constant (neutral.hip --gpus and bench.py draw a random word).\n");
+    }
     for (int joined = 1; joined < g_nranks;) {
       const int fd = accept(ls, NULL, NULL);
       if (fd < 0) {
@@ -166,11 +171,27 @@ void comms_start_from_env(void) {
       struct timeval hs = {5, 0};
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hs, sizeof(hs));
       unsigned long long hello[2] = {0, 0};
-      const int who = recv_or_give_up(fd, hello, sizeof(hello)) ? (int)hello[1] : -1;
-      if (hello[0] != handshake_nonce() || who < 1 || who >= g_nranks || g_peer[who]) {
+      /* (the rank is compared as the 64-bit word it arrives as: 0x1_0000_0001 is not rank 1) */
+      const int heard = recv_or_give_up(fd, hello, sizeof(hello));
+      const int known = heard && hello[0] == handshake_nonce() && hello[1] >= 1 &&
+                        hello[1] < (unsigned long long)g_nranks && !g_peer[(int)hello[1]];
+      /* the caller is told at once whether it is in: a rank that was turned down (its slot
+       * taken, the word wrong) fails there and then, not at the first barrier */
+      const unsigned long long verdict = known ? 1ull : 0ull;
+      if (heard) {
+        (void)send(fd, &verdict, sizeof(verdict), MSG_NOSIGNAL);
+      }
+      if (!known) {
         close(fd);
+        /* strays cost up to the handshake timeout each: a port somebody keeps knocking on
+         * is a reason to stop, not to wait out the launch's whole time limit */
+        if (++rejected > 64) {
+          TERMINATE("rank 0: %d connections to %s:%d that are not ranks of this launch; set "
+                    "NEUTRAL_COMM_PORT to a port of its own.\n", rejected, addr, port);
+        }
         continue;
       }
+      const int who = (int)hello[1];
       /* (from here on no timeout: a rank may be silent for as long as its GPU is busy) */
       struct timeval forever = {0, 0};
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &forever, sizeof(forever));
@@ -195,6 +216,16 @@ void comms_start_from_env(void) {
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
     const unsigned long long hello[2] = {handshake_nonce(), (unsigned long long)g_rank};
     send_all(fd, hello, sizeof(hello));
+    /* in or out, said at once (bounded wait: rank 0 answers a hello within its handshake) */
+    struct timeval hs = {30, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hs, sizeof(hs));
+    unsigned long long verdict = 0;
+    if (!recv_or_give_up(fd, &verdict, sizeof(verdict)) || verdict != 1ull) {
+      TERMINATE("rank %d was turned down by rank 0 at %s:%d (another process holds this rank, or "
+                "NEUTRAL_COMM_NONCE differs between the ranks).\n", g_rank, addr, port);
+    }
+    struct timeval forever = {0, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &forever, sizeof(forever));
     g_peer[0] = fd;
   }
   comms_barrier(); /* everybody is connected before anybody goes on */

@@ -69,7 +69,11 @@ class StepStats(C.Structure):
                 ("tile_cells", C.c_int), ("export_ms", C.c_double),
                 ("checked_arithmetic", C.c_int), ("attempts", C.c_int),
                 ("host_collectives", C.c_int), ("exchange_ranks", C.c_int),
-                ("steals", C.c_uint64)]
+                ("steals", C.c_uint64), ("steals_refused", C.c_uint64),
+                ("stream_hops", C.c_uint64), ("stream_overflows", C.c_uint64),
+                ("stream_batches", C.c_uint64), ("stream_idle_polls", C.c_uint64),
+                ("local_nprocessed", C.c_uint64), ("exchange_ms", C.c_double),
+                ("exchange_rounds", C.c_int), ("emigrants", C.c_uint64)]
 
 
 # every symbol include/neutral_hip.h declares
@@ -87,7 +91,8 @@ ABI_SYMBOLS = (
     "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
     "neutral_hip_invalidate_particles", "neutral_hip_set_scalar_flux_tally",
     "neutral_hip_comm_start", "neutral_hip_comm_stop", "neutral_hip_comm_rank",
-    "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_set_auto_shard",
+    "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_comm_rccl_version",
+    "neutral_hip_set_auto_shard",
     "neutral_hip_store_count", "neutral_hip_set_decomposition",
     "neutral_hip_clear_decomposition", "neutral_hip_set_source_box", "neutral_hip_store_keys",
     "neutral_hip_comm_allreduce_f64", "neutral_hip_comm_max",
@@ -151,6 +156,8 @@ _lib.neutral_hip_set_source_box.argtypes = [C.c_double] * 4
 _lib.neutral_hip_store_keys.restype = C.c_void_p
 _lib.neutral_hip_store_keys.argtypes = [C.POINTER(Particle)]
 _lib.neutral_hip_comm_allreduce_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+if hasattr(_lib, "neutral_hip_comm_rccl_version"):   # (absent from older builds: same-box A/B runs)
+    _lib.neutral_hip_comm_rccl_version.restype = C.c_int
 _lib.neutral_hip_comm_max.restype = C.c_double
 _lib.neutral_hip_comm_max.argtypes = [C.c_double]
 _lib.neutral_hip_bind_rank_device.argtypes = [C.c_int]

@@ -42,6 +42,17 @@ def test_two_rank_bench_equals_one_rank(tmp_path):
     assert two["exchange"] == {"ranks_summed_over": 2, "host_collectives_per_step": 0}
     assert one["exchange"]["ranks_summed_over"] == 1
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    # what a first multi-GPU record needs to be read: every rank's own view of the run
+    rk = two["ranks"]
+    assert "ranks" not in one
+    assert rk["transport_asked"] == "host" and rk["transport_per_rank"] == ["host", "host"]
+    assert isinstance(rk["rccl_version"], int) and rk["rccl_version"] >= 0
+    for key in ("device_ms_per_step", "stream_ms_per_step", "collide_ms_per_step",
+                "exchange_ms_per_step", "particles_alive_last_step", "particles_in_shard"):
+        assert len(rk[key]["per_rank"]) == 2 and rk[key]["min"] <= rk[key]["max"], key
+    assert rk["device_ms_per_step"]["min"] > 0 and rk["exchange_ms_per_step"]["min"] > 0
+    assert sum(rk["particles_in_shard"]["per_rank"]) == 3000001
+    assert 0 < sum(rk["particles_alive_last_step"]["per_rank"]) <= 3000001
     assert "host" in two["config"]["tally_exchange"]
     assert two["events"] == one["events"]                      # exact event totals
     assert two["global_tally"] == pytest.approx(one["global_tally"], rel=1e-12)

@@ -147,6 +147,105 @@ def test_histories_taken_over_by_another_wave(iface, make_problem, cs, monkeypat
     assert sum(s.steals for s in alone[3]) == 0
 
 
+def test_a_slow_thief_is_waited_for(iface, make_problem, cs, monkeypatch):
+    """The owner of a ring does not store into it while a thief is still copying what it took
+    (round-3 advisor finding: only timing kept the two apart).  NEUTRAL_STEAL_DELAY makes every
+    thief sleep between its take and its copy -- far longer than the owner's next time slice --
+    with the smallest rings that are taken from (NEUTRAL_STEAL_MIN=1) on a small grid, so that
+    the owners' hand-backs wrap round to the places the thief has yet to read.  Same bits as
+    the over-particle kernel, no history lost or run twice (the event counts say so)."""
+    prob = make_problem("split", nx=200, nparticles=300000, iterations=1, dt=5.0e-7)
+    want = _run(iface, prob, cs, 0, 1)
+    monkeypatch.setenv("NEUTRAL_STEAL_MIN", "1")
+    monkeypatch.setenv("NEUTRAL_STEAL_DELAY", "400")   # x 64 sleep units: tens of microseconds
+    monkeypatch.setenv("NEUTRAL_K2_MAX_BLOCKS", "512")
+    got = _run(iface, prob, cs, 2, 1)
+    _same(want, got)
+    assert sum(s.steals for s in got[3]) > 50
+    assert sum(s.requeued for s in got[3]) > 0
+    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3])
+
+
+def test_two_stores_stepped_in_turn_on_two_streams(iface, make_problem, cs, monkeypatch):
+    """The words the collision stage's stealing works on belong to the tiled workspace and are
+    reset by a kernel on the stream of the launch that uses them (they were process-wide
+    symbols reset through pointers cached in function statics).  Two particle stores stepped
+    in turn, each on a stream of its own, with stealing on: each ends with the bits the
+    over-particle kernel gives it."""
+    import torch
+    a_prob = make_problem("split", nx=200, nparticles=1000000, iterations=2, dt=5.0e-7)
+    b_prob = make_problem("csp", nx=128, nparticles=300000, iterations=2, dt=1.0e-6)
+    want_a = _run(iface, a_prob, cs, 0, 2)
+    want_b = _run(iface, b_prob, cs, 0, 2)
+    monkeypatch.setenv("NEUTRAL_STEAL_MIN", "1")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    a = iface.Simulation(a_prob, *cs, variant=2)
+    b = iface.Simulation(b_prob, *cs, variant=2)
+    a.inject()
+    b.inject()
+    torch.cuda.synchronize()
+    ev_a, ev_b, steals = [], [], 0
+    for tt in (1, 2):
+        iface.set_stream(sa.cuda_stream)
+        r = a.step(tt)
+        ev_a.append((r.nprocessed, r.facets, r.collisions, r.census))
+        steals += r.stats.steals
+        iface.set_stream(sb.cuda_stream)
+        r = b.step(tt)
+        ev_b.append((r.nprocessed, r.facets, r.collisions, r.census))
+        steals += r.stats.steals
+    iface.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got_a = (a.particle_arrays(), a.tally_host(), ev_a, None)
+    got_b = (b.particle_arrays(), b.tally_host(), ev_b, None)
+    a.close()
+    b.close()
+    _same(want_a, got_a)
+    _same(want_b, got_b)
+    assert steals > 0
+
+
+@pytest.mark.parametrize("deck,nx,n,dt,steps,tile", [
+    ("stream", 400, 200000, None, 2, 16),    # every history crosses ~9 windows per step
+    ("stream", 1000, 100000, None, 1, 128),  # tile = window: every crossing of a tile edge is a hop
+    ("csp", 128, 200000, 4.0e-6, 3, 16),     # long steps: flights outrun the window, then collide
+])
+def test_migrants_change_tiles_inside_the_launch(iface, make_problem, cs, monkeypatch, deck, nx, n, dt,
+                                                 steps, tile):
+    """The asynchronous tile queue: a history that leaves its tally window with far to go is
+    handed, inside the stream kernel, to the queue of the tile it has reached, and whichever
+    workgroup claims it streams it on under a window centred there -- no sort, no further pass.
+    Same bits as the over-particle kernel; the step takes ONE stream pass where the pass
+    mechanism (NEUTRAL_STREAM_QUEUES=0) takes several, with the same bits again; and a queue too
+    small for what a tile receives (NEUTRAL_STREAM_QUEUE_CAPACITY) overflows into passes, same
+    bits again."""
+    kw = dict(nx=nx, nparticles=n, iterations=steps)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    want = _run(iface, prob, cs, 0, steps)
+    monkeypatch.setenv("NEUTRAL_TILE_CELLS", str(tile))
+    monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    got = _run(iface, prob, cs, 2, steps)
+    _same(want, got)
+    assert all(s.aborted == 0 for s in got[3])
+    assert sum(s.stream_hops for s in got[3]) > n // 4
+    assert all(s.stream_overflows == 0 for s in got[3])
+    assert all(s.stream_passes == 1 for s in got[3])
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "0")
+    passes = _run(iface, prob, cs, 2, steps)
+    _same(want, passes)
+    assert all(s.stream_hops == 0 for s in passes[3])
+    assert max(s.stream_passes for s in passes[3]) > 1
+    monkeypatch.delenv("NEUTRAL_STREAM_QUEUES")
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUE_CAPACITY", "64")
+    tight = _run(iface, prob, cs, 2, steps)
+    _same(want, tight)
+    assert sum(s.stream_overflows for s in tight[3]) > 0
+    assert sum(s.stream_hops for s in tight[3]) > 0
+    assert all(s.aborted == 0 for s in tight[3])
+
+
 def test_tile_edge_follows_the_particle_density(iface, make_problem, cs):
     for deck, nx, n, want in (("csp", 100, 100000, 16), ("csp", 200, 100000, 32),
                               ("csp", 400, 100000, 64), ("stream", 1000, 20000, 128)):
@@ -161,10 +260,17 @@ def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, 
     """From the second step of a problem on, stream passes, collision queue and
     collision stage are enqueued on what the step before needed: the only wait is the
     read-back of the counters.  The stream deck makes every history migrate through
-    several windows, i.e. several passes per step."""
+    several windows: inside ONE launch of the stream kernel with the tile queues (the default),
+    through several passes per step without them (NEUTRAL_STREAM_QUEUES=0: the route a full
+    queue still takes)."""
     monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
     prob = make_problem("stream", nx=400, nparticles=30000, iterations=4)
     want = _run(iface, prob, cs, 0, 4)
+    got = _run(iface, prob, cs, 2, 4)
+    _same(want, got)
+    assert all(s.stream_passes == 1 and s.stream_hops > 30000 for s in got[3])
+    assert all(s.host_syncs == 1 for s in got[3][1:])
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "0")
     got = _run(iface, prob, cs, 2, 4)
     _same(want, got)
     stats = got[3]
@@ -181,8 +287,11 @@ def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, 
 
 def test_a_step_that_outruns_the_plan_is_finished(iface, make_problem, cs, monkeypatch):
     """Step 1 at a tiny dt needs one stream pass; step 2 (same store, ten times the
-    dt through a second problem object) needs several more than were enqueued."""
+    dt through a second problem object) needs several more than were enqueued.  (The pass
+    mechanism on its own, NEUTRAL_STREAM_QUEUES=0: with the tile queues a step takes one pass
+    however far its histories fly.)"""
     monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "0")
     short = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-9)
     long_ = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-7)
 

@@ -44,6 +44,20 @@ TARGETS = {
 MEASURED = os.path.join(ROOT, "profiles", "valu_cycles.json")
 
 
+def source_sha16():
+    """sha256 (first 16 hex digits) of the device sources the listing was compiled from: what
+    bench.py compares with the sources it finds, so that a stale listing is flagged, not priced
+    with silently."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "neutral_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def load_costs():
     try:
         with open(MEASURED) as f:
@@ -157,8 +171,10 @@ def main():
         import sys
         mix = {t: json.loads(subprocess.check_output([sys.executable, os.path.abspath(__file__), t,
                                                       "--json"])) for t in sorted(TARGETS)}
+        out_mix = dict(mix)
+        out_mix["source_sha16"] = source_sha16()  # (of neutral_amd/csrc as `make asm` compiled it)
         with open(os.path.join(ROOT, "profiles", "isa_mix.json"), "w") as f:
-            json.dump(mix, f, indent=1)
+            json.dump(out_mix, f, indent=1)
         for t, m in mix.items():
             print(f"{t}: {m['valu_instructions']} VALU per trip, {m['issue_cycles_per_trip']:.0f} cycles, "
                   f"mean {m['mean_cycles_per_valu']:.3f} ({m['mean_cycles_per_valu_low']:.3f}-"
