@@ -287,6 +287,12 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
  * the tally is accumulated with hardware f64 atomics (-munsafe-fp-atomics), which do
  * nothing on fine-grained or host-mapped memory. */
 void neutral_hip_set_lazy_export(int lazy);
+/* Tiled variant: on != 0 lets a history that leaves the tally window it streams under change
+ * tiles INSIDE the stream kernel (a queue per tile, claimed by whichever workgroup is free:
+ * "asynchronous tile queue") instead of waiting for another sort-and-stream pass.  Same
+ * particle bits either way.  Off by default: measured level with the passes on the dense decks
+ * and slower on the sparse ones.  Also: NEUTRAL_STREAM_QUEUES=1. */
+void neutral_hip_set_stream_queues(int on);
 void neutral_hip_sync_particles(NeutralHipParticle* particles);
 void neutral_hip_invalidate_particles(NeutralHipParticle* particles);
 /* ---- scalar-flux tally -------------------------------------------------------------

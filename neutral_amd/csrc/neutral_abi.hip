@@ -110,6 +110,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.steal_min = 0;
   a.steal_delay = 0;
   a.occupancy_rows = 0;
+  a.share_weight = 1;
   /* Default (eager) mode: the SoA arrays are current when the call returns.  One
    * export pass at the end of the step does that (5.9 ms at 1e8 particles); letting
    * every kernel that ends a history store it to the arrays itself -- eleven

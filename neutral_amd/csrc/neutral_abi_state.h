@@ -198,7 +198,8 @@ struct State {
   int tiled_particles = 0;
   int tiled_tiles = 0;
   int tiled_chunks = 0;
-  size_t queue_places = 0; /* tile queues of the stream kernel: places allocated, for how many tiles */
+  int stream_queues = 0;   /* neutral_hip_set_stream_queues: the stream kernel's tile queues are in use */
+  size_t queue_places = 0; /* ... places allocated, for how many tiles */
   int queue_tiles = 0;
 };
 

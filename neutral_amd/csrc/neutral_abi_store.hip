@@ -238,10 +238,12 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
    * neighbours), at least 4 096 places, 4 GiB of logs at most, of which only what is used is ever
    * touched (a tile that receives more overflows into the pass mechanism:
    * NeutralHipStepStats.stream_overflows).
-   * NEUTRAL_STREAM_QUEUES=0 (A/B and tests): none, every migrant waits for the next pass. */
+   * Off by default (measured: at best level with the pass mechanism, slower on sparse decks --
+   * DESIGN.md section 4 item 12); neutral_hip_set_stream_queues(1) or NEUTRAL_STREAM_QUEUES=1
+   * turn them on. */
   {
     const char* switch_env = getenv("NEUTRAL_STREAM_QUEUES");
-    const bool off = switch_env && atoi(switch_env) == 0;
+    const bool off = !(switch_env ? atoi(switch_env) != 0 : g.stream_queues != 0);
     size_t cap = ((size_t)nparticles + 1023) & ~(size_t)1023;
     cap = cap < 4096 ? 4096 : (cap > ((size_t)1 << 22) ? ((size_t)1 << 22) : cap);
     while ((size_t)t.ntiles * cap * sizeof(unsigned) > ((size_t)4 << 30) && cap > 1024) {
@@ -635,6 +637,8 @@ void neutral_hip_reinject_particles(const int nparticles, const int local_nx,
 }
 
 void neutral_hip_set_lazy_export(int lazy) { g.lazy_export = lazy; }
+
+void neutral_hip_set_stream_queues(int on) { g.stream_queues = on ? 1 : 0; }
 
 void neutral_hip_sync_particles(NeutralHipParticle* particles) {
   (void)particles; /* at most one store has a pending write-back */

@@ -171,6 +171,9 @@ struct SolveArgs {
                                  (NEUTRAL_STEAL_DELAY; 0 in production) */
   int occupancy_rows;         /* collision stage: workgroups per CU resident together, among
                                  which the kernel picks how many work (0: all) */
+  int share_weight;           /* collision stage: how many times the others' share of the queue
+                                 the waves of the launch's first row of workgroups start with (the
+                                 oldest wave of a SIMD is served first; 1: equal shares) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
                                  since before it are left alone by the write-back pass */
   /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,

@@ -296,9 +296,11 @@ constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is 
  *   * Who shares a CU is read from the hardware (HW_ID, XCC_ID): every wave enters itself
  *     in the list of its key at the start of the launch.  Same CU on purpose: what a wave
  *     stored went through the L1 the thief reads through, and lies in the L2 both share.
- *     The key is a LOCALITY hint, not what correctness rests on:
+ *     What correctness rests on is less than that: the key's XCC id (waves of one list run on
+ *     one XCD, whose L2 is where a drained plain store is), and
  *       - every successful take is followed by an agent-scope acquire (the thief's L1 holds
- *         nothing stale of the records and ring words it is about to read);
+ *         nothing stale of the records and ring words it is about to read: the CU bits of the
+ *         key may be wrong, the take is still right);
  *       - a key that collects more than kCuWavesMax waves does not name one CU (the decode is
  *         wrong on this part, or the launch is not the shape the lists assume): the launch
  *         then steals nothing (StealWork::overfull; counted in StepCounters::steal_refused
@@ -314,6 +316,9 @@ constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is 
  *     so which wave finishes a history changes nothing it computes.
  *   * The words live in the tiled workspace (StealWork, neutral_kernels.h): one per workspace,
  *     reset by steal_reset_kernel on the launch's own stream -- not process-wide symbols. */
+constexpr int kOldestWeight = 5; /* share of the queue a wave of the launch's first row starts with,
+                                    in shares of the others (SolveArgs::share_weight) */
+constexpr int kWeightedShareMin = 256; /* ... from this many histories per wave on */
 constexpr int kStealMin = 96; /* waiting histories a ring must hold to be taken from
                                                (SolveArgs::steal_min; 0: no stealing) */
 
@@ -380,10 +385,7 @@ template <bool kQueue>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
-    /* (write-through: a record that ends here shares its 128-byte lines with records that are
-     * handed back to a ring and may be taken over by another wave -- no line of the record array
-     * is left dirty in an L2 by this kernel: neutral_history.h) */
-    store_record_through(h, a, a.rec[pid], state);
+    store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
   } else {
@@ -507,7 +509,57 @@ void history_regroup_kernel(SolveArgs a) {
   const bool pooled = kQueue && a.susp && a.steal && ((long long)nwork <= (long long)nwaves * kPoolMaxShare) &&
                       nwaves <= kRingCtlSlots;
   const int gw = block_index * (kBlock / 64) + (int)(threadIdx.x >> 6);
-  const int share = (pooled && gw < nwork) ? (nwork - gw + nwaves - 1) / nwaves : 0;
+  /* Shares in proportion to what a wave is SERVED.  A SIMD issues for its oldest ready wave
+   * first: of the four waves it holds (one of each of the CU's four workgroups: rows 0..3 of the
+   * launch, row 0 dispatched first) the oldest gets ~60 % of the issue slots while all four are
+   * there (7 100 collision passes against 1 500 each: collision_wave_exit_times.log of round 3).
+   * With equal shares it is through long before the others -- stealing then moves work to it, but
+   * only from rings of a hundred and more, and not at all at the share size an 8-GPU rank holds.
+   * So the waves of row 0 start with kOldestWeight times the share of the others (5 : 1 : 1 : 1,
+   * i.e. 62.5 % of a SIMD's histories), and stealing evens out what is left.  The queue is dealt
+   * out to VIRTUAL waves (strided, as before), of which a wave of row 0 owns kOldestWeight
+   * consecutive ones: ring position k of a wave is entry vbase + k % w + (k / w) * nvirtual.
+   * Only with all four rows at work (a full launch); otherwise w = 1 and nothing changes. */
+  /* (... and only where an equal share is kWeightedShareMin histories and more: below that the
+   * three smaller shares no longer fill their waves' lanes -- the 8-GPU share of csp, a hundred
+   * histories per wave, runs 2 % slower weighted, the full size 1 % faster:
+   * profiles/r04/experiments/share_weight_ab.log) */
+  const bool weighted = pooled && a.occupancy_rows == 4 && block_count == (int)gridDim.x && (nwaves % 16) == 0 &&
+                        a.share_weight > 1 && (long long)nwork >= (long long)nwaves * kWeightedShareMin;
+  const int oldest_weight = weighted ? a.share_weight : 1;
+  const int sum_weight = oldest_weight + 3;
+  const int nvirtual = weighted ? (nwaves / 4) * sum_weight : nwaves;
+  struct RingMap {
+    int vbase, w, share;
+  };
+  auto ring_map = [&](int wave) -> RingMap {
+    RingMap m;
+    if (weighted) {
+      const int cu = wave >> 4, row = (wave >> 2) & 3, simd = wave & 3;
+      m.w = (row == 0) ? oldest_weight : 1;
+      m.vbase = cu * (4 * sum_weight) + simd * sum_weight + ((row == 0) ? 0 : oldest_weight + row - 1);
+    } else {
+      m.w = 1;
+      m.vbase = wave;
+    }
+    /* entries of the queue this wave owns: whole rounds of its w virtual waves, and of the last,
+     * partial round those that still lie inside the queue (a prefix: positions stay contiguous) */
+    int n = 0;
+    if (m.vbase < nwork) {
+      const int rounds = (nwork - m.vbase - 1) / nvirtual; /* (full rounds before the last one) */
+      const int last = nwork - m.vbase - rounds * nvirtual; /* (> 0: entries left in the last round) */
+      n = rounds * m.w + ((last < m.w) ? last : m.w);
+    }
+    m.share = n;
+    return m;
+  };
+  auto ring_index = [&](const RingMap& m, int pos) -> size_t {
+    const int j = (m.w == 1) ? 0 : pos % m.w;
+    const int round = (m.w == 1) ? pos : pos / m.w;
+    return (size_t)(m.vbase + j) + (size_t)round * (size_t)nvirtual;
+  };
+  const RingMap my_ring = pooled ? ring_map(gw) : RingMap{0, 1, 0};
+  const int share = my_ring.share;
   /* the ring's control word is a.steal->ring_ctl[gw] (StealWork); these are the owner's own view */
   unsigned w_steals = 0;
   unsigned w_steal_refused = 0;
@@ -590,7 +642,8 @@ void history_regroup_kernel(SolveArgs a) {
       if (best < steal_min || best < 2u) {
         return false;
       }
-      const int v_share = (nwork - v + nwaves - 1) / nwaves;
+      const RingMap v_ring = ring_map(v);
+      const int v_share = v_ring.share;
       /* half of it -- but a wave's worth where there is one: what a thief takes it runs in
        * passes of its own, and a half-empty pass costs the SIMD what a full one costs */
       unsigned take = best / 2u;
@@ -626,9 +679,9 @@ void history_regroup_kernel(SolveArgs a) {
       for (unsigned i = (unsigned)lane; i < take; i += 64u) {
         unsigned pos = v_head + i;
         pos = (pos >= (unsigned)v_share) ? pos - (unsigned)v_share : pos;
-        const unsigned e = __hip_atomic_load(a.queue + ((size_t)v + (size_t)pos * (size_t)nwaves),
+        const unsigned e = __hip_atomic_load(a.queue + ring_index(v_ring, (int)pos),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.queue + ((size_t)gw + (size_t)i * (size_t)nwaves), e, __ATOMIC_RELAXED,
+        __hip_atomic_store(a.queue + ring_index(my_ring, (int)i), e, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT); /* this wave's ring, from position 0 */
       }
       drain_stores(); /* (the loads have returned, the copies are where a later thief sees them) */
@@ -647,7 +700,7 @@ void history_regroup_kernel(SolveArgs a) {
   unsigned w_collide_passes = 0;
   /* ring position -> queue entry (pos < 2 * share) */
   auto ring_slot = [&](int pos) -> unsigned* {
-    return a.queue + ((size_t)gw + (size_t)((pos >= share) ? pos - share : pos) * (size_t)nwaves);
+    return a.queue + ring_index(my_ring, (pos >= share) ? pos - share : pos);
   };
   if (pooled) {
     drained = (share == 0);
@@ -732,12 +785,14 @@ void history_regroup_kernel(SolveArgs a) {
       const int rank = lane_rank(m_refill);
       if (want == kWantRefill && rank < n_take) {
         const SolveArgs c = NEUTRAL_COLD_ARGS(a);
-        /* (ring words and records may have been written by another wave of this launch -- the
-         * owner's own hand-back, a CU-mate it took them from: loads that bypass the L1) */
+        /* (ring words and records may have been written by another wave of this launch: the
+         * owner's own hand-back -- through the L1 this wave reads through -- or a CU-mate's that
+         * this wave took over, after the acquire its take ended with) */
         const unsigned e = __hip_atomic_load(ring_slot(ring_head + rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pid = (int)(e & ~kRequeued);
-        SuspendExtra x; /* (asked for with the record, one wait for both; looked at if it is valid) */
-        load_record_through(h, c, c.rec[pid], &c.susp[pid], x);
+        SuspendExtra x;
+        load_record(h, c, c.rec[pid]);
+        x = c.susp[pid];
         resume<kSameTables, kChecked>(h, c, ix); /* counted as processed by the suspender */
         if (e & kRequeued) {
           h.energy_deposition = x.energy_deposition;
@@ -856,14 +911,17 @@ void history_regroup_kernel(SolveArgs a) {
         unsigned readers = __hip_atomic_load(&sw->ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (out) {
           const SolveArgs c = NEUTRAL_COLD_ARGS(a);
-          /* write-through: whoever reads them next -- a lane of this wave, or a wave that
-           * takes them from this ring -- reads around its L1 (neutral_history.h) */
-          store_record_through(h, c, c.rec[pid], kRecCollide);
+          /* (plain stores: they are in the XCD's L2 -- the L1 writes through -- once the wave
+           * has waited for them below, which is where a wave of the same XCD that takes them
+           * over reads them after its acquire.  Writing them through to memory and reading them
+           * around the L1 was measured too: +1.5 % on the stage, for a property the lists do not
+           * need -- their key carries the XCC id) */
+          store_record(h, c, c.rec[pid], kRecCollide);
           SuspendExtra x;
           x.energy_deposition = h.energy_deposition;
           x.counter = h.counter;
           x.nevents = h.nevents;
-          store_through16(&c.susp[pid], x);
+          c.susp[pid] = x;
           if (kFlux) {
             __hip_atomic_store(&c.susp_track[pid], h.track_length, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -901,7 +959,7 @@ void history_regroup_kernel(SolveArgs a) {
           if (kQueue && c.decomposed && outside_domain(h, c)) {
             /* into another rank's cells: the history waits to be sent (its RNG counter
              * travels in the record) */
-            store_record_through(h, c, c.rec[pid], kRecEmigrate);
+            store_record(h, c, c.rec[pid], kRecEmigrate);
             c.slot_info[pid] = slot_summary(kRecEmigrate, 0, 0, c.tiles_x, c.tile_shift);
             atomicAdd(c.emigrants, 1u);
             want = kWantRefill;
@@ -1329,6 +1387,13 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
         const char* force = getenv("NEUTRAL_STEAL_MIN"); /* (tests: small rings taken from too) */
         if (force && atoi(force) >= 0) {
           k.steal_min = atoi(force);
+        }
+      }
+      k.share_weight = kOldestWeight;
+      {
+        const char* w = getenv("NEUTRAL_SHARE_WEIGHT"); /* (A/B and tests: 1 = equal shares) */
+        if (w && atoi(w) >= 1 && atoi(w) <= 16) {
+          k.share_weight = atoi(w);
         }
       }
       k.steal_delay = 0;

@@ -107,11 +107,22 @@ enum Ctrl : int {
 };
 /* ---- the asynchronous tile queue (TiledArgs::queue_entries) ---- */
 constexpr unsigned kQueueEmpty = 0xFFFFFFFFu; /* a place that is reserved but not written yet */
-/* a workgroup prefers a queue over a fresh chunk from this many waiting histories on (one per
- * lane): migrants are worked off while the tiles they came from are still being streamed,
- * instead of piling up for a pass of their own */
+/* Which queue a workgroup takes from, in this order:
+ *   - the queue of the tile its window is centred on, while kQueueStayMin histories wait there
+ *     (no window to flush and move);
+ *   - a fresh chunk;
+ *   - the first tile -- counted on from its own, every workgroup a different way round -- where
+ *     a workgroup's worth waits (kQueueBatchMin: one history per lane), else the fullest.
+ * Two policies that were tried first (profiles/r04/experiments/queue_policy_ab.log): every
+ * workgroup to the FULLEST queue -- all 256 sweep at about the same time, agree on the tile and
+ * split it into scraps: stream 4000^2 at 75 ms against the pass mechanism's 36, 57 % of the
+ * workgroup time spent polling; and the queue whose head is OLDEST (entries tagged with how much
+ * of their step lies behind them), which herds worse: 242 ms. */
+constexpr unsigned kQueueStayMin = 256;
 constexpr unsigned kQueueBatchMin = 1024;
-constexpr unsigned kQueueBatchMax = 4096; /* histories a workgroup claims at a time */
+constexpr unsigned kQueueBatchMax = 4096; /* histories a workgroup claims at a time: four per
+                                             lane, so that lanes whose history was short are
+                                             refilled instead of waiting for their wave's longest */
 /* polls of a workgroup that finds nothing to do while histories are still in flight elsewhere
  * (each a sweep over the tiles' counters and a sleep: several microseconds) before it gives up
  * and reports the launch as aborted -- seconds; a launch lasts milliseconds */
@@ -733,7 +744,11 @@ __device__ __forceinline__ bool far_to_go(const History& h, const TiledArgs& t) 
   return facets_ahead > kMigrateMinFacets;
 }
 
-template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked>
+/* kQueues: the asynchronous tile queue is compiled in (TiledArgs::queue_entries: a property of
+ * the kernel, like the flux and the decomposition -- merely carrying the queue code costs the
+ * default instantiation 7 % of csp's stream stage in scalar and vector spills around the chunk
+ * loop: profiles/r04/experiments/queue_policy_ab.log) */
+template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked, bool kQueues>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
   constexpr int kWindows = kFlux ? 2 : 1;
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       t.edges_computed && __builtin_amdgcn_readfirstlane(*t.edges_computed) != 0;
   /* histories without a window move on after a window's worth of facets when the
    * pass has windows to offer (wave-uniform) */
-  const bool budget_on = t.allow_migrate && (t.queue_entries != nullptr || t.ctrl[kCtrlWindowed] != 0);
+  const bool budget_on = t.allow_migrate && (kQueues || t.ctrl[kCtrlWindowed] != 0);
   int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
   int win_ox = 0;
   int win_oy = 0;
@@ -802,7 +817,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   int pid = -1;
 
   /* the tile queues are in use (wave-uniform): migrants change tiles inside this launch */
-  const bool queues = t.queue_entries != nullptr && t.allow_migrate;
+  const bool queues = kQueues && t.allow_migrate;
   const unsigned qcap = t.queue_capacity;
   unsigned w_ended = 0;     /* histories this wave has ended for this launch since its last report */
   unsigned w_hops = 0;
@@ -822,15 +837,60 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
     unsigned polls = 0;
     for (;;) {
       __syncthreads(); /* the previous work is complete (also orders the staging above) */
+      /* a claim on a tile's queue: places [head, head + m) of its log (thread 0) */
+      auto claim = [&](int tile, unsigned at_least) -> bool {
+        for (;;) {
+          const unsigned head = __hip_atomic_load(&t.queue_head[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned tail = __hip_atomic_load(&t.queue_tail[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tail = (tail > qcap) ? qcap : tail;
+          if (tail <= head || tail - head < at_least) {
+            return false; /* (others were quicker) */
+          }
+          unsigned m = tail - head;
+          m = (m > kQueueBatchMax) ? kQueueBatchMax : m;
+          if (atomicCAS(&t.queue_head[tile], head, head + m) == head) {
+            s_cursor = (int)head;
+            s_end = (int)(head + m);
+            s_tile = tile;
+            s_windowed = 1;
+            return true;
+          }
+        }
+      };
       if (threadIdx.x == 0) {
         s_best = 0u;
         s_best_tile = -1;
-        s_kind = kWorkNone;
+        int kind = kWorkNone;
+        /* stay where the window is, or take a fresh chunk: no sweep */
+        if (queues && cur_tile >= 0 && claim(cur_tile, kQueueStayMin)) {
+          kind = kWorkQueue;
+          wg_batches++;
+        }
+        if (kind == kWorkNone &&
+            __hip_atomic_load(&t.ctrl[kCtrlChunkHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks) {
+          const int c = (int)atomicAdd(&t.ctrl[kCtrlChunkHead], 1u);
+          if (c < nchunks) {
+            const uint4 ch = t.chunks[c];
+            s_cursor = (int)ch.x;
+            s_end = (int)ch.y;
+            s_tile = (int)ch.z;
+            s_windowed = (int)ch.w;
+            kind = kWorkChunk;
+          }
+        }
+        s_kind = kind;
       }
       __syncthreads();
-      if (queues) {
-        /* sweep: the fullest queue (ties and near-ties broken differently by every workgroup
-         * and poll, so that workgroups looking at the same moment spread over the tiles) */
+      if (__builtin_amdgcn_readfirstlane(s_kind) != kWorkNone) {
+        break;
+      }
+      if (!queues) {
+        break; /* (no queues: out of chunks is out of work) */
+      }
+      /* sweep over the tiles' queues: the first tile after this workgroup's own where a
+       * workgroup's worth waits; if there is none, the fullest */
+      {
+        const int start = (cur_tile >= 0) ? cur_tile : (int)((blockIdx.x * 2654435761u) % (unsigned)t.ntiles);
         unsigned mine = 0u;
         int mine_tile = -1;
         for (int tile = (int)threadIdx.x; tile < t.ntiles; tile += kStreamBlock) {
@@ -838,10 +898,16 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           const unsigned head = __hip_atomic_load(&t.queue_head[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tail = (tail > qcap) ? qcap : tail;
           if (tail > head) {
-            unsigned waiting = tail - head;
-            waiting = (waiting > 0xFFFFFu) ? 0xFFFFFu : waiting;
-            const unsigned salt = ((unsigned)tile * 2654435761u + blockIdx.x * 40503u + polls * 9973u) >> 20;
-            const unsigned key = (waiting << 12) | salt;
+            const unsigned waiting = tail - head;
+            unsigned key;
+            if (waiting >= kQueueBatchMin) {
+              int ahead = tile - start;
+              ahead += (ahead < 0) ? t.ntiles : 0;
+              key = 0x80000000u | (unsigned)(t.ntiles - ahead);
+            } else {
+              const unsigned salt = ((unsigned)tile * 2654435761u + blockIdx.x * 40503u + polls * 9973u) >> 22;
+              key = (waiting << 10) | salt;
+            }
             if (key > mine) {
               mine = key;
               mine_tile = tile;
@@ -860,68 +926,38 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         }
         __syncthreads();
         if (mine != 0u && mine == s_best) {
-          s_best_tile = mine_tile; /* (equal keys: equally full, either will do) */
+          s_best_tile = mine_tile; /* (equal keys: equally good, either will do) */
         }
         __syncthreads();
       }
       if (threadIdx.x == 0) {
-        const unsigned waiting = queues ? (s_best >> 12) : 0u;
         int kind = kWorkNone;
-        /* a claim on a tile's queue: places [head, head + m) of its log */
-        auto claim = [&](int tile) -> bool {
-          for (;;) {
-            const unsigned head = __hip_atomic_load(&t.queue_head[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned tail = __hip_atomic_load(&t.queue_tail[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tail = (tail > qcap) ? qcap : tail;
-            if (tail <= head) {
-              return false; /* (others were quicker) */
-            }
-            unsigned m = tail - head;
-            m = (m > kQueueBatchMax) ? kQueueBatchMax : m;
-            if (atomicCAS(&t.queue_head[tile], head, head + m) == head) {
-              s_cursor = (int)head;
-              s_end = (int)(head + m);
-              s_tile = tile;
-              s_windowed = 1;
-              return true;
-            }
-          }
-        };
-        if (waiting >= kQueueBatchMin && claim(s_best_tile)) {
-          kind = kWorkQueue;
-        }
-        if (kind == kWorkNone &&
-            __hip_atomic_load(&t.ctrl[kCtrlChunkHead], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nchunks) {
-          const int c = (int)atomicAdd(&t.ctrl[kCtrlChunkHead], 1u);
-          if (c < nchunks) {
-            const uint4 ch = t.chunks[c];
-            s_cursor = (int)ch.x;
-            s_end = (int)ch.y;
-            s_tile = (int)ch.z;
-            s_windowed = (int)ch.w;
-            kind = kWorkChunk;
-          }
-        }
-        if (kind == kWorkNone && waiting > 0u && claim(s_best_tile)) {
+        if (s_best != 0u && claim(s_best_tile, 1u)) {
           kind = kWorkQueue;
         }
         s_kind = kind;
         if (kind == kWorkQueue) {
           wg_batches++;
-        } else if (kind == kWorkNone) {
-          wg_idle_polls++;
         }
         /* nothing to take: is anything still in flight?  (s_chunk < 0: the workgroup leaves) */
         s_chunk = 0;
         if (kind == kWorkNone) {
-          const unsigned live = queues ? __hip_atomic_load(&t.ctrl[kCtrlLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-          if (live == 0u || waiting > 0u) {
-            s_chunk = (live == 0u) ? -1 : 0; /* (a queue had something a moment ago: look again at once) */
+          const unsigned live = __hip_atomic_load(&t.ctrl[kCtrlLive], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (live == 0u) {
+            s_chunk = -1;
+          } else if (s_best != 0u) {
+            /* (a queue had something a moment ago: look again at once) */
           } else if (polls >= kQueueIdlePollsMax) {
             atomicAdd(&a.counters->aborted, 1u); /* (histories in flight that never arrive: a defect) */
             s_chunk = -1;
           } else {
-            __builtin_amdgcn_s_sleep(32);
+            /* (idle workgroups back off: 255 of them sweeping every few microseconds is a
+             * load on the L2 the working ones feel) */
+            wg_idle_polls++;
+            const unsigned nap = (polls < 5u) ? polls : 5u;
+            for (unsigned k = 0; k < (1u << nap); ++k) {
+              __builtin_amdgcn_s_sleep(64);
+            }
           }
         }
       }
@@ -1198,16 +1234,11 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             census<kChecked>(h, a, tally);
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
-          /* (with the tile queues in use EVERY record of this launch is stored write-through and
-           * read around the L1: one protocol for every access to an array whose 128-byte lines
-           * are shared by records that change hands.  tools/micro/handoff_litmus.hip measures
-           * that protocol; its variant 4 -- a plain last store -- showed no stale read either,
-           * but a plain store leaves a dirty line in this XCD's L2 that nothing here needs) */
-          if (queues) {
-            store_record_through(h, a, t.rec_out[pid], kRecIdle);
-          } else {
-            store_record(h, a, t.rec_out[pid], kRecIdle);
-          }
+          /* (a plain store: nobody picks this record up again in this launch.  Records that
+           * change hands share 128-byte lines with it; tools/micro/handoff_litmus.hip variant 4 is
+           * this mix -- write-through hand-offs, plain last stores -- with no stale read in 1e7
+           * hops, and writing all 1e8 last records of csp through cost the stream kernel 3 ms) */
+          store_record(h, a, t.rec_out[pid], kRecIdle);
           /* (its reach class: where the next step's pass 0 puts it inside its tile) */
           t.info_out[pid] = slot_summary(
               kRecIdle, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
@@ -1275,11 +1306,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       if (park != kRecIdle && !queued) {
         if (!hop) { /* (a migrant whose queue was full has its record in place already) */
-          if (queues) {
-            store_record_through(h, a, t.rec_out[pid], park);
-          } else {
-            store_record(h, a, t.rec_out[pid], park);
-          }
+          store_record(h, a, t.rec_out[pid], park);
         }
         t.info_out[pid] = slot_summary(
             park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
@@ -1668,24 +1695,32 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
   };
   /* (scalar flux and spatial decomposition are compile-time properties of the kernel:
    * the default instantiation carries no trace of either) */
-  switch ((a.checked ? 8 : 0) | (a.same_tables ? 4 : 0) | (a.flux_tally ? 2 : 0) |
-          (a.decomposed ? 1 : 0)) {
-    case 15: launch(stream_kernel<true, true, true, true>); break;
-    case 14: launch(stream_kernel<true, true, false, true>); break;
-    case 13: launch(stream_kernel<true, false, true, true>); break;
-    case 12: launch(stream_kernel<true, false, false, true>); break;
-    case 11: launch(stream_kernel<false, true, true, true>); break;
-    case 10: launch(stream_kernel<false, true, false, true>); break;
-    case 9: launch(stream_kernel<false, false, true, true>); break;
-    case 8: launch(stream_kernel<false, false, false, true>); break;
-    case 7: launch(stream_kernel<true, true, true, false>); break;
-    case 6: launch(stream_kernel<true, true, false, false>); break;
-    case 5: launch(stream_kernel<true, false, true, false>); break;
-    case 4: launch(stream_kernel<true, false, false, false>); break;
-    case 3: launch(stream_kernel<false, true, true, false>); break;
-    case 2: launch(stream_kernel<false, true, false, false>); break;
-    case 1: launch(stream_kernel<false, false, true, false>); break;
-    default: launch(stream_kernel<false, false, false, false>); break;
+  auto launch_for = [&](auto queues_tag) {
+    constexpr bool kQ = decltype(queues_tag)::value;
+    switch ((a.checked ? 8 : 0) | (a.same_tables ? 4 : 0) | (a.flux_tally ? 2 : 0) |
+            (a.decomposed ? 1 : 0)) {
+      case 15: launch(stream_kernel<true, true, true, true, kQ>); break;
+      case 14: launch(stream_kernel<true, true, false, true, kQ>); break;
+      case 13: launch(stream_kernel<true, false, true, true, kQ>); break;
+      case 12: launch(stream_kernel<true, false, false, true, kQ>); break;
+      case 11: launch(stream_kernel<false, true, true, true, kQ>); break;
+      case 10: launch(stream_kernel<false, true, false, true, kQ>); break;
+      case 9: launch(stream_kernel<false, false, true, true, kQ>); break;
+      case 8: launch(stream_kernel<false, false, false, true, kQ>); break;
+      case 7: launch(stream_kernel<true, true, true, false, kQ>); break;
+      case 6: launch(stream_kernel<true, true, false, false, kQ>); break;
+      case 5: launch(stream_kernel<true, false, true, false, kQ>); break;
+      case 4: launch(stream_kernel<true, false, false, false, kQ>); break;
+      case 3: launch(stream_kernel<false, true, true, false, kQ>); break;
+      case 2: launch(stream_kernel<false, true, false, false, kQ>); break;
+      case 1: launch(stream_kernel<false, false, true, false, kQ>); break;
+      default: launch(stream_kernel<false, false, false, false, kQ>); break;
+    }
+  };
+  if (t.queue_entries) {
+    launch_for(std::true_type{});
+  } else {
+    launch_for(std::false_type{});
   }
   return hipGetLastError();
 }

@@ -88,7 +88,7 @@ ABI_SYMBOLS = (
     "neutral_hip_set_quiet", "neutral_hip_set_tests_file", "neutral_hip_last_step",
     "neutral_hip_set_arithmetic",
     "neutral_hip_reinject_particles", "neutral_hip_free_particles",
-    "neutral_hip_set_lazy_export", "neutral_hip_sync_particles",
+    "neutral_hip_set_lazy_export", "neutral_hip_set_stream_queues", "neutral_hip_sync_particles",
     "neutral_hip_invalidate_particles", "neutral_hip_set_scalar_flux_tally",
     "neutral_hip_comm_start", "neutral_hip_comm_stop", "neutral_hip_comm_rank",
     "neutral_hip_comm_nranks", "neutral_hip_comm_transport", "neutral_hip_comm_rccl_version",
@@ -263,6 +263,12 @@ def set_tests_file(path: str) -> None:
 
 def set_lazy_export(lazy: bool) -> None:
     _lib.neutral_hip_set_lazy_export(1 if lazy else 0)
+
+
+def set_stream_queues(on: bool) -> None:
+    """Tiled variant: migrants change tiles inside the stream kernel (include/neutral_hip.h)."""
+    if hasattr(_lib, "neutral_hip_set_stream_queues"):
+        _lib.neutral_hip_set_stream_queues(1 if on else 0)
 
 
 def comm_start() -> int:

@@ -144,7 +144,7 @@ def test_flux_windows_at_every_tile_edge(iface, make_problem, cs, monkeypatch, t
     sim.inject()
     r = sim.step(1)
     assert r.stats.tile_cells == (tile if tile <= 64 else 64)
-    assert r.stats.stream_hops > 30000    # histories did change windows (inside the launch)
+    assert r.stats.stream_passes > 1      # histories did change windows
     flux, tally = sim.flux.cpu().numpy(), sim.tally_host()
     touched = flux > 0
     assert np.array_equal(touched, tally > 0)

@@ -212,11 +212,12 @@ def test_two_stores_stepped_in_turn_on_two_streams(iface, make_problem, cs, monk
 ])
 def test_migrants_change_tiles_inside_the_launch(iface, make_problem, cs, monkeypatch, deck, nx, n, dt,
                                                  steps, tile):
-    """The asynchronous tile queue: a history that leaves its tally window with far to go is
+    """The asynchronous tile queue (neutral_hip_set_stream_queues / NEUTRAL_STREAM_QUEUES=1): a
+    history that leaves its tally window with far to go is
     handed, inside the stream kernel, to the queue of the tile it has reached, and whichever
     workgroup claims it streams it on under a window centred there -- no sort, no further pass.
     Same bits as the over-particle kernel; the step takes ONE stream pass where the pass
-    mechanism (NEUTRAL_STREAM_QUEUES=0) takes several, with the same bits again; and a queue too
+    mechanism (the default) takes several, with the same bits again; and a queue too
     small for what a tile receives (NEUTRAL_STREAM_QUEUE_CAPACITY) overflows into passes, same
     bits again."""
     kw = dict(nx=nx, nparticles=n, iterations=steps)
@@ -226,6 +227,7 @@ def test_migrants_change_tiles_inside_the_launch(iface, make_problem, cs, monkey
     want = _run(iface, prob, cs, 0, steps)
     monkeypatch.setenv("NEUTRAL_TILE_CELLS", str(tile))
     monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "1")
     got = _run(iface, prob, cs, 2, steps)
     _same(want, got)
     assert all(s.aborted == 0 for s in got[3])
@@ -237,7 +239,7 @@ def test_migrants_change_tiles_inside_the_launch(iface, make_problem, cs, monkey
     _same(want, passes)
     assert all(s.stream_hops == 0 for s in passes[3])
     assert max(s.stream_passes for s in passes[3]) > 1
-    monkeypatch.delenv("NEUTRAL_STREAM_QUEUES")
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "1")
     monkeypatch.setenv("NEUTRAL_STREAM_QUEUE_CAPACITY", "64")
     tight = _run(iface, prob, cs, 2, steps)
     _same(want, tight)
@@ -260,17 +262,17 @@ def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, 
     """From the second step of a problem on, stream passes, collision queue and
     collision stage are enqueued on what the step before needed: the only wait is the
     read-back of the counters.  The stream deck makes every history migrate through
-    several windows: inside ONE launch of the stream kernel with the tile queues (the default),
-    through several passes per step without them (NEUTRAL_STREAM_QUEUES=0: the route a full
-    queue still takes)."""
+    several windows: through several passes per step (the default), or inside ONE launch of the
+    stream kernel with the tile queues (NEUTRAL_STREAM_QUEUES=1)."""
     monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
     prob = make_problem("stream", nx=400, nparticles=30000, iterations=4)
     want = _run(iface, prob, cs, 0, 4)
+    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "1")
     got = _run(iface, prob, cs, 2, 4)
     _same(want, got)
     assert all(s.stream_passes == 1 and s.stream_hops > 30000 for s in got[3])
     assert all(s.host_syncs == 1 for s in got[3][1:])
-    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "0")
+    monkeypatch.delenv("NEUTRAL_STREAM_QUEUES")
     got = _run(iface, prob, cs, 2, 4)
     _same(want, got)
     stats = got[3]
@@ -287,11 +289,8 @@ def test_a_steady_state_step_waits_for_the_device_once(iface, make_problem, cs, 
 
 def test_a_step_that_outruns_the_plan_is_finished(iface, make_problem, cs, monkeypatch):
     """Step 1 at a tiny dt needs one stream pass; step 2 (same store, ten times the
-    dt through a second problem object) needs several more than were enqueued.  (The pass
-    mechanism on its own, NEUTRAL_STREAM_QUEUES=0: with the tile queues a step takes one pass
-    however far its histories fly.)"""
+    dt through a second problem object) needs several more than were enqueued."""
     monkeypatch.setenv("NEUTRAL_WINDOW_MIN_PARTICLES", "32")
-    monkeypatch.setenv("NEUTRAL_STREAM_QUEUES", "0")
     short = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-9)
     long_ = make_problem("stream", nx=400, nparticles=30000, iterations=2, dt=1.0e-7)
 

@@ -9,7 +9,7 @@ the collision pass: Threefry's rotations; v_mul_f64 for the facet loop: the smal
 with a dozen of them is the facet trip).
 
   python tools/isa_histogram.py collide     # history_regroup_kernel<true,true,false,false>
-  python tools/isa_histogram.py facet       # stream_kernel<true,false,false,false>
+  python tools/isa_histogram.py facet       # stream_kernel<true,false,false,false,false>
   python tools/isa_histogram.py collide --json
 """
 import argparse
@@ -31,10 +31,10 @@ TARGETS = {
     # (the compiler names it in the block comments): <kChecked=0, kCachedReciprocals=1,
     # kDomain=0, kCarryTargets=1, kComputedEdges=1, WindowCellTallyT<flux=0, uniform=0|1>>
     "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
-              "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
+              "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
               r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb0EEE"),
     "facet_uniform": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
-                      "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
+                      "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
                       r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb1EEE"),
 }
 
