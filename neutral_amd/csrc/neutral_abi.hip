@@ -117,6 +117,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
    * scattered 8-byte stores per history -- cost 18 ms (profiles/r02: fused export). */
   const bool pass_export = tiled && !g.lazy_export;
   a.export_skip_long_dead = 0;
+  a.export_view = nullptr;
   a.decomposed = decomposed ? 1 : 0;
   a.emigrants = nullptr;
   a.abort_flag = (const int*)g.d_check; /* low word of tables_check_kernel's verdict */
@@ -303,6 +304,33 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         a.flux_tally = step_flux((size_t)nx * (size_t)ny);
       }
     }
+    /* The write-back in two parts, when under half of the particles went to the collision stage
+     * last step (csp: a tenth): the pass over the ids of everybody else runs on a stream of lowest
+     * priority BESIDE the collision stage instead of after it (their records are final when the
+     * stream kernel is through), and the collision stage writes the final state of the histories
+     * it ends to the arrays itself (eleven scattered stores each, behind its arithmetic).
+     * NEUTRAL_SPLIT_EXPORT=0: the one pass. */
+    neutral::SplitExport split = {};
+    split.on = false;
+    if (pass_export && !decomposed && g.suspended_share >= 0.0 && g.suspended_share < 0.5) {
+      const char* off = getenv("NEUTRAL_SPLIT_EXPORT");
+      split.on = !(off && atoi(off) == 0);
+    }
+    a.export_view = nullptr;
+    g.tiled.mark_suspended = 0;
+    if (split.on) {
+      g.h_export_view = a.p;
+      HIP_CHECK(hipMemcpyAsync(g.d_export_view, &g.h_export_view, sizeof(a.p), hipMemcpyHostToDevice,
+                               g.stream));
+      HIP_CHECK(hipMemsetAsync(g.tiled.susp_ids, 0, sizeof(unsigned) * g.susp_id_words, g.stream));
+      a.export_view = g.d_export_view;
+      g.tiled.mark_suspended = 1;
+      split.side = g.export_stream;
+      split.done = g.ev_split_done;
+      split.p = a.p;
+      split.skip_long_dead = a.export_skip_long_dead;
+
+    }
     HIP_CHECK(hipEventRecord(g.ev_start, g.stream));
     if (tiled) {
       /* Stream passes are enqueued on what the last step needed (plus one, which
@@ -312,7 +340,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       plan.stream_passes = g.plan_passes > 0 ? g.plan_passes + 1 : 2;
       plan.blocks_per_cu = -1; /* the collision stage sizes itself from its queue */
       HIP_CHECK(neutral::launch_solve_tiled(a, g.tiled, g.stream, plan, 0, g.ev_sorted,
-                                            g.ev_streamed, g.ev_collected, &passes));
+                                            g.ev_streamed, g.ev_collected, &passes, &split));
     } else {
       HIP_CHECK(neutral::launch_solve(a, g.variant, g.stream));
     }
@@ -320,13 +348,21 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     if (exchange) {
       exchange_step(a, energy_deposition_tally, tiled); /* (beside the write-back below) */
     }
-    if (pass_export && !decomposed) {
+    if (split.on) {
+      /* (the pass beside the collision stage: the caller's stream goes on when it is through) */
+      HIP_CHECK(neutral::launch_split_export(a, g.tiled, split, g.ev_collected));
+      HIP_CHECK(hipStreamWaitEvent(g.stream, g.ev_split_done, 0));
+    } else if (pass_export && !decomposed) {
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
       HIP_CHECK(neutral::launch_export_records(
           g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, a.abort_flag,
           a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
+    /* (whatever else this step enqueues -- more passes for a step that outran its plan -- is
+     * followed by the one pass over everybody) */
+    a.export_view = nullptr;
+    g.tiled.mark_suspended = 0;
 
     if (exchange) {
       finish_exchange();
@@ -476,6 +512,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     t.id_out = swap_id;
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
+    g.suspended_share = (double)queue_total /
+                        ((double)(a.nparticles > 0 ? a.nparticles : 1) * (double)neutral::comm_nranks());
     /* the graveyard grows by what the sort carried over a step ago; what it carried over
      * now joins next step (ctrl[8]: the first slot of the dead this step's sort found) */
     t.mirror_end = t.sort_end;

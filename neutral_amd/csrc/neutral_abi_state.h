@@ -198,6 +198,15 @@ struct State {
   int tiled_particles = 0;
   int tiled_tiles = 0;
   int tiled_chunks = 0;
+  /* the write-back split in two (neutral_kernels.h: SplitExport): the stream its first part runs
+   * on beside the collision stage, its event, and what share of the particles the last step of
+   * this record store handed to the collision stage (< 0: not known; the split pays below a half) */
+  hipStream_t export_stream = nullptr;
+  hipEvent_t ev_split_done = nullptr;
+  neutral::ParticleView* d_export_view = nullptr; /* the stepped store's array pointers, for the */
+  neutral::ParticleView h_export_view = {};        /* collision stage's own write-back */
+  double suspended_share = -1.0;
+  size_t susp_id_words = 0;
   int stream_queues = 0;   /* neutral_hip_set_stream_queues: the stream kernel's tile queues are in use */
   size_t queue_places = 0; /* ... places allocated, for how many tiles */
   int queue_tiles = 0;

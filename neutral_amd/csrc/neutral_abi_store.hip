@@ -38,6 +38,14 @@ void ensure_scratch() {
   HIP_CHECK(hipEventCreate(&g.ev_exchanged));
   HIP_CHECK(hipEventCreate(&g.ev_exchange_begins));
   HIP_CHECK(hipStreamCreateWithFlags(&g.comm_stream, hipStreamNonBlocking));
+  {
+    /* (lowest priority: what runs there gets the CUs the caller's stream leaves free) */
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_CHECK(hipStreamCreateWithPriority(&g.export_stream, hipStreamNonBlocking, least));
+    HIP_CHECK(hipEventCreateWithFlags(&g.ev_split_done, hipEventDisableTiming));
+    HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
+  }
   if (!g.h_results) {
     HIP_CHECK(hipHostMalloc((void**)&g.h_results, sizeof(StepResults), hipHostMallocMapped));
     memset(g.h_results, 0, sizeof(StepResults));
@@ -137,6 +145,7 @@ void sync_soa() {
  * layout changes): the next tiled step imports it again. */
 void drop_records() {
   g.rec_valid = false;
+  g.suspended_share = -1.0;
   g.free_count = 0; /* (slots emigrants left are holes of the records, not of the arrays) */
   g.plan_passes = 0;
 }
@@ -174,6 +183,9 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     const size_t nb = (size_t)(tx * ty * 4 + 2); /* (up to four reach classes per tile) */
     HIP_CHECK(hipMalloc((void**)&t.order, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.collide_queue, sizeof(unsigned) * n));
+    if (t.susp_ids) HIP_CHECK(hipFree(t.susp_ids));
+    g.susp_id_words = (n + 31) / 32;
+    HIP_CHECK(hipMalloc((void**)&t.susp_ids, sizeof(unsigned) * g.susp_id_words));
     HIP_CHECK(hipMalloc((void**)&t.rec_in, sizeof(neutral::ParticleRec) * n));
     HIP_CHECK(hipMalloc((void**)&t.rec_out, sizeof(neutral::ParticleRec) * n));
     HIP_CHECK(hipMalloc((void**)&t.info_in, sizeof(unsigned) * n));

@@ -176,6 +176,11 @@ struct SolveArgs {
                                  oldest wave of a SIMD is served first; 1: equal shares) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
                                  since before it are left alone by the write-back pass */
+  /* [device] the SoA store's array pointers, when the collision stage writes the final state
+   * of every history it ends to the arrays itself -- so that the write-back of everybody else
+   * can run beside it (TiledArgs::susp_ids; null: it does not).  Read where a history ends,
+   * not held in registers through the collision loop. */
+  const ParticleView* export_view;
   /* spatial domain decomposition: this rank owns cells [x_off, x_off + nx) x [y_off,
    * y_off + ny) of a larger mesh; a history that crosses out of them is stored as an
    * emigrant instead of going on (0: the rank owns the whole mesh) */
@@ -221,6 +226,12 @@ struct TiledArgs {
   unsigned* tile_cursor;   /* nsort + 2: next free position of each bucket during placement */
   uint4* chunks;           /* max_chunks: {begin, end, tile, windowed} into order[] */
   unsigned* collide_queue; /* nparticles: ids suspended at their first collision */
+  /* one bit per particle id: handed to the collision stage in this step.  Set by the kernel
+   * that builds the collision queue when the write-back is split (mark_suspended): the pass over
+   * the ids leaves those alone -- the collision stage exports them itself -- and can therefore
+   * run BESIDE the collision stage, on a stream of lowest priority. */
+  unsigned* susp_ids;
+  int mark_suspended;
   SuspendExtra* susp;      /* nparticles: side store of the collision stage's time slicing */
   double* susp_track;      /* nparticles, only with the scalar-flux tally (else null) */
   StealWork* steal;        /* the collision stage's rings and CU lists (neutral_kernels.hip) */
@@ -328,7 +339,17 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
                                  const ParticleView& p, int n, hipStream_t stream,
                                  const int* abort_flag = nullptr,
                                  const unsigned* first_inactive = nullptr,
-                                 unsigned final_from = 0xFFFFFFFFu);
+                                 unsigned final_from = 0xFFFFFFFFu,
+                                 const unsigned* skip_ids = nullptr, int max_blocks = 0);
+/* the write-back split in two (see TiledArgs::susp_ids): what launch_solve_tiled enqueues on a
+ * stream of its own, beside the collision stage, when `on` */
+struct SplitExport {
+  bool on;
+  hipStream_t side;      /* (low priority: it gets the CUs the collision stage's waves leave) */
+  hipEvent_t done;       /* recorded on `side` after the pass */
+  ParticleView p;
+  int skip_long_dead;
+};
 const unsigned* tiled_first_inactive(const TiledArgs& t);
 /* spatial domain decomposition (neutral_tiled.hip, section 2b): emigrants of this
  * step's records (t.rec_out) counted and packed by destination rank, arrivals appended
@@ -367,7 +388,10 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
                               const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
                               hipEvent_t after_stream, hipEvent_t after_collect,
-                              int* passes_enqueued);
+                              int* passes_enqueued, const SplitExport* split = nullptr);
+hipError_t launch_split_export(const SolveArgs& a, const TiledArgs& t, const SplitExport& split,
+                               hipEvent_t after_collect);
+
 
 /* builds start[0..nbuckets] of the bucketed index for `keys` (neutral_device.h) */
 hipError_t launch_build_cs_index(const double* keys, int n, int shift, long long base,

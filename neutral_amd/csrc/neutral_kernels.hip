@@ -388,6 +388,18 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
     store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
+    if (a.export_view) {
+      /* the interface's arrays get the final state here (the write-back of the histories that
+       * never came to this stage runs beside it: TiledArgs::susp_ids) -- eleven scattered
+       * stores per history ended, behind the stage's arithmetic: measured free, where a pass over
+       * the marked ids after the stage costs 1.2 ms (profiles/r04/experiments/split_export_ab.log).
+       * The eleven array pointers are fetched from memory: as kernel arguments they would be
+       * live through the collision loop and push it into scratch */
+      const ParticleView* pv = a.export_view;
+      asm volatile("" : "+s"(pv)); /* (not foldable back into the kernel arguments) */
+      store_particle_view(h, *pv, (int)h.id);
+    }
+
   } else {
     store_particle(h, a, pid);
   }

@@ -416,8 +416,14 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
       const bool susp = ((mine >> k) & 1u) != 0;
       const unsigned long long m = __ballot(susp);
       if (susp) {
-        t.collide_queue[s_base + s_count[k][wave] + (unsigned)lane_rank(m)] =
-            (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+        const unsigned slot = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+        t.collide_queue[s_base + s_count[k][wave] + (unsigned)lane_rank(m)] = slot;
+        if (t.mark_suspended) {
+          /* (whose history the collision stage ends, and exports: the pass over the ids that
+           * runs beside it leaves these alone) */
+          const unsigned id = t.rec_out[slot].id;
+          atomicOr(&t.susp_ids[id >> 5], 1u << (id & 31u));
+        }
       }
     }
   }
@@ -462,17 +468,22 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
                                                                     ParticleView p, int n,
                                                                     const int* abort_flag,
                                                                     const unsigned* first_inactive,
-                                                                    unsigned final_from) {
+                                                                    unsigned final_from,
+                                                                    const unsigned* skip_ids) {
   if (abort_flag && *abort_flag) {
     return; /* the step's kernels have done nothing: rec holds an older step */
   }
-  const int k = blockIdx.x * kSortBlock + threadIdx.x;
-  if (k < n) {
+  /* (a grid smaller than the ids strides over them: the pass beside the collision stage) */
+  for (long long kk = (long long)blockIdx.x * kSortBlock + threadIdx.x; kk < n; kk += (long long)gridDim.x * kSortBlock) {
+    const int k = (int)kk;
+    if (skip_ids && ((skip_ids[k >> 5] >> (k & 31)) & 1u)) {
+      continue; /* in the collision stage's hands (it may be rewriting the record right now) */
+    }
     const unsigned slot = slot_of_id[k];
     /* (the boundary as the step's sort found it, on the device -- or, written back on demand,
      * as the host remembers it from when the arrays were last current) */
     if (slot >= (first_inactive ? *first_inactive : final_from)) {
-      return; /* dead since before the step began: the arrays have its final state, and the
+      continue; /* dead since before the step began: the arrays have its final state, and the
                  random access to its record -- what this pass is bound by -- is saved */
     }
     const ParticleRec r = rec[slot];
@@ -1651,11 +1662,12 @@ hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsign
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream,
                                  const int* abort_flag, const unsigned* first_inactive,
-                                 unsigned final_from) {
+                                 unsigned final_from, const unsigned* skip_ids, int max_blocks) {
   if (n > 0) {
-    const int grid = (n + kSortBlock - 1) / kSortBlock;
+    int grid = (n + kSortBlock - 1) / kSortBlock;
+    grid = (max_blocks > 0 && grid > max_blocks) ? max_blocks : grid;
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
-                       slot_of_id, p, n, abort_flag, first_inactive, final_from);
+                       slot_of_id, p, n, abort_flag, first_inactive, final_from, skip_ids);
   }
   return hipGetLastError();
 }
@@ -1728,7 +1740,7 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
 hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stream,
                               const TiledPlan& plan, int first_pass, hipEvent_t after_sort,
                               hipEvent_t after_stream, hipEvent_t after_collect,
-                              int* passes_enqueued) {
+                              int* passes_enqueued, const SplitExport* split) {
   if (passes_enqueued) {
     *passes_enqueued = first_pass;
   }
@@ -1819,5 +1831,19 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   return launch_solve(c, kVariantEventSorted, stream);
 }
+
+/* the write-back of every history that did NOT go to the collision stage, on a stream of its own
+ * (lowest priority), enqueued behind the collision stage's launch: it needs the collision
+ * queue's marks (after_collect) and gets the CUs that stage's waves free */
+hipError_t launch_split_export(const SolveArgs& a, const TiledArgs& t, const SplitExport& split,
+                               hipEvent_t after_collect) {
+  (void)hipStreamWaitEvent(split.side, after_collect, 0);
+  (void)launch_export_records(t.rec_out, t.slot_of_id, split.p, a.nparticles, split.side, a.abort_flag,
+                              split.skip_long_dead ? &t.ctrl[kCtrlFirstInactive] : nullptr, 0xFFFFFFFFu,
+                              t.susp_ids);
+  (void)hipEventRecord(split.done, split.side);
+  return hipGetLastError();
+}
+
 
 }  // namespace neutral

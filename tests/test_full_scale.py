@@ -37,21 +37,23 @@ def _rel(a, b):
 
 
 def test_headline_size_against_the_oracle(iface, make_problem, cs):
-    """csp 400^2 with 1e8 particles (the configuration BASELINE.json's metric is quoted on), two
-    timesteps -- the second has 2.6e9 collisions in the dense block, time-sliced rings and
-    stealing in the collision stage -- default pipeline, default write-back, against the oracle
-    on the host's cores: per-step (nprocessed, facets, collisions, census) exact, cellx / celly /
-    dead exact for every particle, floating state 1e-9, per-cell tally L2 <= 1e-9, same zero
-    pattern."""
-    n, steps = 100000000, 2
+    """csp 400^2 with 1e8 particles (the configuration BASELINE.json's metric is quoted on), five
+    timesteps -- the first two are flight (a free flight drawn in the vacuum outlasts its step:
+    omp3/neutral.c:127-131; only a history that BEGINS a step inside the dense block collides),
+    the next three put the collision stage's time-sliced rings and stealing to work -- default pipeline, default write-back, against the oracle on
+    the host's cores: per-step (nprocessed, facets, collisions, census) exact, cellx / celly /
+    dead exact for every particle, floating state 1e-9 (positions absolute: the mesh is one
+    unit wide and 1e8 samples include x = 1e-7), per-cell tally L2 <= 1e-9, same zero pattern."""
+    n, steps = 100000000, 5
     prob = make_problem("csp", nx=400, nparticles=n, iterations=steps)
-    threads = min(32, os.cpu_count() or 1)
+    threads = min(64, os.cpu_count() or 1)
     ob.lib().orc_set_num_threads(threads)
     ref = ob.OracleRun(prob, *cs)
     ref.inject()
     sim = iface.Simulation(prob, *cs, variant=2)
     sim.inject()
     steals = 0
+    sum_collisions = 0
     for tt in range(1, steps + 1):
         g = sim.step(tt)
         c = ref.step(tt)
@@ -62,18 +64,20 @@ def test_headline_size_against_the_oracle(iface, make_problem, cs):
             (c.nprocessed, c.facets, c.collisions, c.census)
         assert g.stats.aborted == 0 and g.stats.steals_refused == 0
         steals += g.stats.steals
+        sum_collisions += g.collisions
     tg, tc = sim.tally_host(), ref.tally
     l2 = float(np.linalg.norm(tg - tc) / np.linalg.norm(tc))
     print(f"per-cell tally L2 {l2:.3e}; global sum rel "
           f"{abs(tg.sum() - tc.sum()) / abs(tc.sum()):.3e}; steals {steals}", flush=True)
     assert l2 < TALLY_L2_TOL
     assert np.array_equal(tg == 0.0, tc == 0.0)
+    assert sum_collisions > 100000000 and steals > 0, "the run no longer reaches the dense block"
     gp, cp = sim.particle_arrays(), ref.particles.as_dict()
     for f in ("cellx", "celly", "dead"):
         assert np.array_equal(gp[f], cp[f]), f
-    for f in ("energy", "weight", "dt_to_census", "x", "y"):
+    for f in ("energy", "weight", "dt_to_census"):
         assert _rel(gp[f], cp[f]) < STATE_TOL, f
-    for f in ("omega_x", "omega_y"):
+    for f in ("omega_x", "omega_y", "x", "y"):
         assert float(np.max(np.abs(gp[f] - cp[f]))) < STATE_TOL, f
     print(f"{n} particles: cells and death flags equal, floating state within {STATE_TOL}", flush=True)
     sim.close()
