@@ -418,6 +418,13 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
       if (susp) {
         const unsigned slot = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
         t.collide_queue[s_base + s_count[k][wave] + (unsigned)lane_rank(m)] = slot;
+        if (t.mark_suspended) {
+          /* (whose history the collision stage ends, and exports: the pass over the ids that
+           * runs beside it leaves these alone.  Marked here -- a random 4-byte read of the id
+           * per suspended record -- or by the stream kernel where it suspends: level, same box) */
+          const unsigned id = t.rec_out[slot].id;
+          atomicOr(&t.susp_ids[id >> 5], 1u << (id & 31u));
+        }
       }
     }
   }
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
                                                                     const int* abort_flag,
                                                                     const unsigned* first_inactive,
                                                                     unsigned final_from,
-                                                                    const unsigned* skip_ids, int getenv_nt) {
+                                                                    const unsigned* skip_ids) {
   if (abort_flag && *abort_flag) {
     return; /* the step's kernels have done nothing: rec holds an older step */
   }
@@ -480,17 +487,7 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
       continue; /* dead since before the step began: the arrays have its final state, and the
                  random access to its record -- what this pass is bound by -- is saved */
     }
-    ParticleRec r;
-    if (skip_ids && getenv_nt) { /* TEMPORARY A/B: the pass beside the collision stage reads around the caches */
-      typedef unsigned v4u __attribute__((ext_vector_type(4)));
-      const v4u* src = (const v4u*)&rec[slot];
-      v4u q[5];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) q[i] = __builtin_nontemporal_load(&src[i]);
-      __builtin_memcpy(&r, q, 80);
-    } else {
-      r = rec[slot];
-    }
+    const ParticleRec r = rec[slot];
     /* (streamed out once: non-temporal stores keep them from evicting the half-read lines
      * of the records, -15 % on this pass: tools/micro/export_probe.hip) */
     __builtin_nontemporal_store(r.x, &p.x[k]);
@@ -1323,12 +1320,6 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         if (!hop) { /* (a migrant whose queue was full has its record in place already) */
           store_record(h, a, t.rec_out[pid], park);
         }
-        if (park == kRecCollide && t.mark_suspended) {
-          /* (whose history the collision stage ends, and exports: the pass over the ids that
-           * runs beside that stage leaves these alone -- TiledArgs::susp_ids; marked here, where
-           * the id is in a register, not by the kernel that builds the queue from the summaries) */
-          atomicOr(&t.susp_ids[h.id >> 5], 1u << (h.id & 31u));
-        }
         t.info_out[pid] = slot_summary(
             park, h.cellx - a.x_off, h.celly - a.y_off, t.tiles_x, t.tile_shift,
             (t.reach_classes > 1 && park == kRecMigrate)
@@ -1677,8 +1668,7 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
     int grid = (n + kSortBlock - 1) / kSortBlock;
     grid = (max_blocks > 0 && grid > max_blocks) ? max_blocks : grid;
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
-                       slot_of_id, p, n, abort_flag, first_inactive, final_from, skip_ids,
-                       getenv("NEUTRAL_AB_SPLIT_NT") ? 1 : 0);
+                       slot_of_id, p, n, abort_flag, first_inactive, final_from, skip_ids);
   }
   return hipGetLastError();
 }
