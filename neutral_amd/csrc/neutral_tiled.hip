@@ -745,7 +745,11 @@ __host__ __device__ __forceinline__ size_t stream_lds_payload_bytes(const SolveA
   }
   return (lds + 15) & ~(size_t)15;
 }
+#ifdef NEUTRAL_PHASE_CLOCK
+constexpr size_t kStreamLdsControlBytes = 64 + 16 * 9 * 8;
+#else
 constexpr size_t kStreamLdsControlBytes = 64;
+#endif
 
 /* more than kMigrateMinFacets facets ahead of it before the census, at the rate its
  * direction crosses cells? */
@@ -755,6 +759,46 @@ __device__ __forceinline__ bool far_to_go(const History& h, const TiledArgs& t) 
                                        fabs(h.omega_y) * t.cells_per_y);
   return facets_ahead > kMigrateMinFacets;
 }
+
+/* -DNEUTRAL_PHASE_CLOCK: a build that says where the stream kernel's waves spend their time
+ * (shader-clock ticks, summed over waves; tools/micro/phase_clock.py reads and prints them):
+ * 0 taking work + barriers, 1 window flush and move, 2 refill (loads, prologue / resume),
+ * 3 a stream pass outside its facet loop, 5 the facet loop, 6 census / end of a history (its
+ * stores), 7 hand-offs (records of colliders and migrants).  A wave's stamps and sums live in
+ * LDS behind the control words; whichever lane is the first active one where a stamp stands
+ * makes it (the regions are divergent). */
+#ifdef NEUTRAL_PHASE_CLOCK
+__device__ unsigned long long g_phase_clock[8];
+#define PHASE_DECL                                                                              \
+  unsigned long long* const lds_ph =                                                            \
+      (unsigned long long*)((char*)lds_ctl + 64) + (threadIdx.x >> 6) * 9;                      \
+  if ((threadIdx.x & 63) == 0) {                                                                \
+    lds_ph[0] = __builtin_readcyclecounter();                                                   \
+    for (int k = 1; k <= 8; ++k) lds_ph[k] = 0;                                                 \
+  }
+#define PHASE(k)                                                                                \
+  do {                                                                                          \
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {        \
+      const unsigned long long ph_now = __builtin_readcyclecounter();                           \
+      lds_ph[1 + (k)] += ph_now - lds_ph[0];                                                    \
+      lds_ph[0] = ph_now;                                                                       \
+    }                                                                                           \
+  } while (0)
+#define PHASE_REPORT                                                                            \
+  if ((threadIdx.x & 63) == 0) {                                                                \
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_clock[k], lds_ph[1 + k]);                    \
+  }
+extern "C" void neutral_hip_debug_phase_clock(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_clock), sizeof(unsigned long long) * 8);
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), zero, sizeof(zero));
+}
+#else
+#define PHASE_DECL
+#define PHASE(k)
+#define PHASE_REPORT
+#endif
 
 /* kQueues: the asynchronous tile queue is compiled in (TiledArgs::queue_entries: a property of
  * the kernel, like the flux and the decomposition -- merely carrying the queue code costs the
@@ -838,6 +882,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   unsigned wg_idle_polls = 0;
   enum : int { kWorkChunk = 0, kWorkQueue = 1, kWorkNone = 2 };
 
+  PHASE_DECL
   for (;;) {
     if (queues && (threadIdx.x & 63) == 0 && w_ended) {
       atomicSub(&t.ctrl[kCtrlLive], w_ended);
@@ -983,6 +1028,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
      * compiler they are wave-uniform, so the chunk bookkeeping and the window
      * origin stay on the scalar unit) */
     const int work = __builtin_amdgcn_readfirstlane(s_kind);
+    PHASE(0);
     if (work == kWorkNone) {
       break;
     }
@@ -1009,6 +1055,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       win_oy = ((cur_tile / t.tiles_x) << t.tile_shift) - margin;
       __syncthreads();
     }
+    PHASE(1);
     /* does every cell of the window, and around it, hold one density?  (wave-uniform) */
     const bool uniform_window =
         windowed && t.tile_uniform &&
@@ -1124,6 +1171,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
           }
         }
+        PHASE(2);
       } else if (has) {
         /* STREAM: up to kStreamRepeat facet crossings (the pass choice above costs
          * ~100 scalar instructions; histories cross ~60 facets in a row), or the
@@ -1161,6 +1209,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               run = !far_to_go(h, t);
             }
           }
+          PHASE(3);
           if (run) {
 #pragma unroll 1
             do {
@@ -1192,6 +1241,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               }
             } while (run);
           }
+          PHASE(5);
           };
           /* ... and for a mesh whose edges the device has found to follow the host layer's
            * formula this step (computed, not loaded) and for any other: four copies, one runs */
@@ -1241,6 +1291,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             atomicAdd(&a.counters->aborted, 1u);
             h.ev = kEvEnd; /* ended like a history whose time has run out, next pass */
           }
+          PHASE(3);
         } else {
           if (h.ev == kEvCensus) {
             census<kChecked>(h, a, tally);
@@ -1261,6 +1312,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           has = false;
           ended = true;
           did_census = (h.ev == kEvCensus);
+          PHASE(6);
         }
       }
       /* ---- histories handed on: the record carries the state ---- */
@@ -1329,6 +1381,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
         has = false;
         ended = true;
       }
+      PHASE(7);
       w_ended += (unsigned)__popcll(__ballot(ended));
       w_migrants += (unsigned)__popcll(__ballot(park == kRecMigrate && !queued));
       if (kDomain) {
@@ -1337,6 +1390,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       w_census += (unsigned)__popcll(__ballot(did_census));
     }
   }
+  PHASE(0);
+  PHASE_REPORT
   /* one atomic per wave for the whole kernel: a per-event add to this single
    * word costs more than the streaming itself (one address takes ~100 adds/us) */
   if ((threadIdx.x & 63) == 0 && w_migrants) {
