@@ -191,6 +191,11 @@ struct WindowCellTallyT {
      * makes the address a shift-or and a shift) */
     const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
     lds_double* const slot = &window[which * (unsigned)(W * W) + cell];
+    /* (this question is asked twice per trip -- here and at the end of cross_facet() -- and a
+     * condition with two uses is kept as a lane mask: s_cselect, s_and with exec,
+     * s_cbranch_vcc, 7 cycles of a SIMD's issue (tools/micro/issue_mix.hip) where a comparison
+     * that feeds ONE branch is s_cmp + s_cbranch_scc, 2.  So the other place asks it of a
+     * copy of the mask that went through an empty asm statement) */
     if (__builtin_expect(m_outside == 0, 1)) {
       /* every lane inside (most trips): the LDS add and nothing else */
       (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -817,6 +822,19 @@ __device__ __forceinline__ bool next_is_facet(History& h) {
   return (h.dt_to_census > 0.0) & crosses & !collides;
 }
 
+/* The same question answered with one comparison: |d_facet| < min(d_census, d_collision).  Never
+ * yes where next_is_facet() says no (dt <= 0 makes d_census <= 0; d_facet below both means
+ * neither comparison of `collides` holds), and no where that says yes only if d_facet equals
+ * d_collision exactly or is negative -- a history this stops is named by decide_carried() from
+ * the same state and crosses on the wave's next pass.  Four comparisons and the scalar logic
+ * that joins their masks become a minimum and a comparison (tools/micro/issue_mix.hip: scalar
+ * instructions are not free beside vector ones). */
+__device__ __forceinline__ bool surely_next_is_facet(const History& h) {
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  return __builtin_fabs(h.distance) < __builtin_fmin(distance_to_census, distance_to_collision);
+}
+
 /* which edges the history aims at on each axis (History::target_ix ...), from its direction */
 __device__ __forceinline__ void aim_targets(History& h, const SolveArgs& a) {
   const bool up_x = (h.omega_x >= 0.0); /* omp3/neutral.c:438-447 */
@@ -1166,7 +1184,10 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   asm volatile("" : "+v"(h.mfp_to_collision), "+v"(h.dt_to_census));
 
   if constexpr (Tally::kUniformDensity) {
-    if (__builtin_expect(tally.m_outside == 0, 1)) {
+    /* (of a copy the compiler cannot merge with the tally's question: see WindowCellTallyT::add) */
+    unsigned long long m_any_outside = tally.m_outside;
+    asm volatile("" : "+s"(m_any_outside));
+    if (__builtin_expect(m_any_outside == 0, 1)) {
       return; /* (no lane outside the window: asked of the wave first, it is a scalar test) */
     }
     if (tally.inside()) {

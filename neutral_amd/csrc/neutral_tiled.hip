@@ -1060,6 +1060,13 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
     const bool uniform_window =
         windowed && t.tile_uniform &&
         __builtin_amdgcn_readfirstlane((int)t.tile_uniform[cur_tile]) != 0;
+    /* may a history that leaves the window wait for another pass?  (all lanes or none: the
+     * wave-uniform condition as a lane mask -- and a mask like any other to the compiler:
+     * knowing it is all or nothing, it selects between the lanes' mask and zero with three
+     * more scalar instructions per facet) */
+    unsigned long long may_migrate =
+        __builtin_amdgcn_readfirstlane((windowed && t.allow_migrate) ? 1 : 0) ? ~0ull : 0ull;
+    asm volatile("" : "+s"(may_migrate));
     /* an un-windowed chunk sees a window that contains no cell */
     tally.ox = __builtin_amdgcn_readfirstlane(windowed ? win_ox : (1 << 30));
     tally.oy = __builtin_amdgcn_readfirstlane(windowed ? win_oy : (1 << 30));
@@ -1187,7 +1194,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
            * is inside it: WindowCellTallyT<, true>), and for any other */
           h.m_x_facet = __builtin_amdgcn_ballot_w64(h.x_facet != 0); /* (decide_carried's) */
           /* (all lanes or none: the wave-uniform condition as a lane mask) */
-          const unsigned long long may_migrate = (windowed && t.allow_migrate) ? ~0ull : 0ull;
+
           auto run_facets = [&](auto uniform_density, auto computed_edges) {
           constexpr bool kUniform = decltype(uniform_density)::value;
           constexpr bool kEdges = decltype(computed_edges)::value;
@@ -1232,7 +1239,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
               /* (what ends the flight is named below the loop, once; `crossed` is the trip
                * count too: every lane in the loop started with it) */
-              run = next_is_facet(h) & (crossed < kStreamRepeat);
+              run = surely_next_is_facet(h) & (crossed < kStreamRepeat);
+              /* (the scalar AND says whether its result is zero: one instruction and a branch) */
               if ((cell_tally.m_outside & may_migrate) != 0) {
                 asm volatile("");
                 if (out_of_window) {
