@@ -125,6 +125,14 @@ typedef __attribute__((address_space(3))) double lds_double;
  * index; two windows of 88 x 88 (121 KB) take its place when the flux is kept */
 constexpr int kWindowCells = 128;
 constexpr int kWindowCellsWithFlux = 88;
+/* A row of the window in LDS is this many cells longer than the window is wide: with rows of
+ * exactly 128 cells (1 KB) the cells of one COLUMN share an LDS bank, and the histories a wave
+ * streams together sit in a patch of neighbouring cells -- rows apart as often as columns
+ * (profiles/r04/experiments/window_row_pad.log) */
+#ifndef NEUTRAL_WINDOW_ROW_PAD
+#define NEUTRAL_WINDOW_ROW_PAD 1
+#endif
+constexpr int kWindowRowPad = NEUTRAL_WINDOW_ROW_PAD;
 
 template <bool kWithFlux>
 struct WindowTallyT {
@@ -132,7 +140,8 @@ struct WindowTallyT {
   static constexpr bool kUniformDensity = false;
   __device__ __forceinline__ bool inside() const { return false; }
   static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
-  lds_double* window; /* LDS, W*W, row-major (flux: the next W*W) */
+  static constexpr int S = W + kWindowRowPad; /* cells per row in LDS */
+  lds_double* window; /* LDS, W rows of S, row-major (flux: the next W rows) */
   int ox;         /* local cell coordinates of window element (0,0) */
   int oy;
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
@@ -143,7 +152,7 @@ struct WindowTallyT {
     const unsigned ly = (unsigned)(celly - oy);
     if (lx < (unsigned)W && ly < (unsigned)W) {
       /* ds_add_f64, no return value */
-      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * W) + ly * (unsigned)W + lx], v,
+      (void)__hip_atomic_fetch_add(&window[which * (unsigned)(W * S) + ly * (unsigned)S + lx], v,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
       unsafeAtomicAdd(mesh_element(mesh, celly * a.nx + cellx), v);
@@ -173,6 +182,7 @@ struct WindowCellTallyT {
    * The stream kernel compiles its facet loop for both kinds of window. */
   static constexpr bool kUniformDensity = kUniform;
   static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
+  static constexpr int S = W + kWindowRowPad; /* cells per row in LDS */
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */
   /* the lanes of the wave whose cell is outside the window (the caller's ballot of
@@ -187,10 +197,10 @@ struct WindowCellTallyT {
   __device__ __forceinline__ bool outside() const { return (lx >= (unsigned)W) | (ly >= (unsigned)W); }
   __device__ __forceinline__ void add(const SolveArgs& a, int pcellx, int pcelly, double v,
                                       unsigned which, double* mesh) const {
-    /* (a power-of-two window: the row and the column share no bit, and saying so -- `|` --
-     * makes the address a shift-or and a shift) */
-    const unsigned cell = ((W & (W - 1)) == 0) ? ((ly * (unsigned)W) | lx) : (ly * (unsigned)W + lx);
-    lds_double* const slot = &window[which * (unsigned)(W * W) + cell];
+    /* (a power-of-two row: the row and the column share no bit, and saying so -- `|` -- makes
+     * the address a shift-or and a shift; any other row length: a multiply-add) */
+    const unsigned cell = ((S & (S - 1)) == 0) ? ((ly * (unsigned)S) | lx) : (ly * (unsigned)S + lx);
+    lds_double* const slot = &window[which * (unsigned)(W * S) + cell];
     /* (this question is asked twice per trip -- here and at the end of cross_facet() -- and a
      * condition with two uses is kept as a lane mask: s_cselect, s_and with exec,
      * s_cbranch_vcc, 7 cycles of a SIMD's issue (tools/micro/issue_mix.hip) where a comparison

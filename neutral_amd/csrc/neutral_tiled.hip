@@ -719,9 +719,11 @@ template <int kW>
 __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window, double* mesh,
                                              int ox, int oy) {
   /* row-contiguous: one wave instruction adds 64 consecutive cells (512 B) */
+  constexpr int kS = kW + kWindowRowPad; /* (cells per row in LDS: neutral_history.h) */
   for (int i = threadIdx.x; i < kW * kW; i += kStreamBlock) {
-    const double v = window[i];
-    window[i] = 0.0;
+    const int at = (i / kW) * kS + (i % kW);
+    const double v = window[at];
+    window[at] = 0.0;
     if (v != 0.0) {
       const int gx = ox + (i % kW);
       const int gy = oy + (i / kW);
@@ -809,13 +811,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
   constexpr int kWindows = kFlux ? 2 : 1;
   extern __shared__ double lds_raw[];
-  double* window = lds_raw;                                             /* kWindows * kW^2 f64 */
-  unsigned short* lds_index = (unsigned short*)(lds_raw + kWindows * kW * kW);
+  constexpr int kWindowDoubles = kW * (kW + kWindowRowPad); /* a window in LDS: kW rows (neutral_history.h) */
+  double* window = lds_raw;                                             /* kWindows of them */
+  unsigned short* lds_index = (unsigned short*)(lds_raw + kWindows * kWindowDoubles);
   /* the workgroup's chunk bookkeeping lives BEHIND the window and the indexes, not in static
    * LDS in front of them: the window then starts at LDS address 0 and a cell's address is a
    * shift and a shift-add, without the add of the static variables' size (one vector
    * instruction per facet) */
-  int* const lds_ctl = (int*)((char*)lds_raw + stream_lds_payload_bytes<kSameTables>(a, kWindows * kW * kW));
+  int* const lds_ctl = (int*)((char*)lds_raw + stream_lds_payload_bytes<kSameTables>(a, kWindows * kWindowDoubles));
   int& s_chunk = lds_ctl[0];
   int& s_end = lds_ctl[1];
   int& s_tile = lds_ctl[2];
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       }
       ix.absorb_index = lds_index + used;
     }
-    for (int i = threadIdx.x; i < kWindows * kW * kW; i += kStreamBlock) {
+    for (int i = threadIdx.x; i < kWindows * kWindowDoubles; i += kStreamBlock) {
       window[i] = 0.0;
     }
   }
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (cur_tile >= 0) {
         flush_window<kW>(a, window, a.tally, win_ox, win_oy);
         if (kFlux) {
-          flush_window<kW>(a, window + kW * kW, a.flux_tally, win_ox, win_oy);
+          flush_window<kW>(a, window + kWindowDoubles, a.flux_tally, win_ox, win_oy);
         }
       }
       cur_tile = chunk_tile;
@@ -1423,7 +1426,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   if (cur_tile >= 0) {
     flush_window<kW>(a, window, a.tally, win_ox, win_oy);
     if (kFlux) {
-      flush_window<kW>(a, window + kW * kW, a.flux_tally, win_ox, win_oy);
+      flush_window<kW>(a, window + kWindowDoubles, a.flux_tally, win_ox, win_oy);
     }
   }
   {
@@ -1651,7 +1654,8 @@ hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, 
 /* ---- launcher ---------------------------------------------------------------------- */
 
 size_t tiled_lds_bytes(const SolveArgs& a) {
-  const int cells = a.flux_tally ? 2 * kWindowCellsWithFlux * kWindowCellsWithFlux : kWindow * kWindow;
+  const int cells = a.flux_tally ? 2 * kWindowCellsWithFlux * (kWindowCellsWithFlux + kWindowRowPad)
+                                 : kWindow * (kWindow + kWindowRowPad);
   return (a.same_tables ? stream_lds_payload_bytes<true>(a, cells)
                         : stream_lds_payload_bytes<false>(a, cells)) +
          kStreamLdsControlBytes;
