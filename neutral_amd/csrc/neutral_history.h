@@ -1025,7 +1025,25 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
   bool reflect;
   unsigned long long m_reflect = 0; /* kCarryTargets: the lanes that reflect */
   int ncellx, ncelly;
-  if (kCarryTargets) {
+  /* Under a window of one density on a mesh whose edges are a formula nothing is LOADED for
+   * the cell a crossing enters, so the step can be made first and the question "was that the
+   * mesh's edge?" asked of its result: the edge number of the axis that moved has left [0, n]
+   * (the other axis' cannot have).  Two comparisons and an OR of their masks, where asking
+   * before the step is two comparisons and six scalar instructions that cut the step's
+   * selects to size (tools/micro/issue_mix.hip: 2-3 cycles of the SIMD's issue each); the
+   * rare lane that did reflect steps back in the branch that turns it round. */
+  constexpr bool kStepFirst = kCarryTargets && kComputedEdges && Tally::kUniformDensity && kDomain == 0;
+  if (kStepFirst) {
+    ncellx = h.cellx + (xf ? h.step_x : 0);
+    ncelly = h.celly + (xf ? 0 : h.step_y);
+    /* (two masks joined on the scalar unit: the ballot of an OR of two comparisons comes out
+     * as a 0/1 vector register and a third comparison) */
+    m_reflect = __builtin_amdgcn_ballot_w64((unsigned)(h.target_ix + (ncellx - h.cellx)) >
+                                            (unsigned)a.global_nx) |
+                __builtin_amdgcn_ballot_w64((unsigned)(h.target_iy + (ncelly - h.celly)) >
+                                            (unsigned)a.global_ny);
+    reflect = __builtin_amdgcn_inverse_ballot_w64(m_reflect);
+  } else if (kCarryTargets) {
     /* (History::step_x ...: the direction tests were made when the history last turned)
      * The axis that moves is picked first, with selects on 32-bit values: written as
      * logic on the two axes' booleans it comes out as 0/1 values in vector registers
@@ -1151,6 +1169,13 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     h.cellx = ncellx;
     h.celly = ncelly;
     if (__builtin_expect(m_reflect != 0, 0)) { /* wave-uniform: most trips of the facet loop skip it */
+      if (kStepFirst) {
+        /* (the step that was the mesh's edge, taken back: the history stays in its cell) */
+        ncellx -= (reflect & xf) ? h.step_x : 0;
+        ncelly -= (reflect & !xf) ? h.step_y : 0;
+        h.cellx = ncellx;
+        h.celly = ncelly;
+      }
       h.omega_x = flip_x ? -h.omega_x : h.omega_x;
       h.u_x_inv = flip_x ? -h.u_x_inv : h.u_x_inv;
       h.omega_y = flip_y ? -h.omega_y : h.omega_y;
@@ -1203,7 +1228,9 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     if (tally.inside()) {
       return; /* the cell entered has the density this history carries */
     }
-    new_density = *mesh_element(a.density, dens_y * a.nx + dens_x); /* (rare, dependent) */
+    /* (of the cell the history IS in: a step taken back at the mesh's edge is back by here) */
+    new_density = kStepFirst ? *mesh_element(a.density, (h.celly - a.y_off) * a.nx + (h.cellx - a.x_off))
+                             : *mesh_element(a.density, dens_y * a.nx + dens_x); /* (rare, dependent) */
   }
   if (__double_as_longlong(new_density) != __double_as_longlong(h.local_density)) {
     h.local_density = new_density;
