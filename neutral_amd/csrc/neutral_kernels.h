@@ -259,6 +259,7 @@ struct TiledArgs {
                               passes used */
   int chunk_particles;     /* particles one workgroup takes at a time */
   int refill_min;          /* stream kernel: empty lanes of a wave that trigger a refill */
+  int stream_repeat;       /* ... facet crossings of a wave per STREAM pass (scheduling only) */
   int pass;                /* 0: every live record starts its history; > 0: migrants resume */
   int allow_migrate;       /* 0 on the last permitted pass: finish with global atomics */
   double cells_per_x;      /* nx / mesh width, ny / mesh height: for the estimate of how */

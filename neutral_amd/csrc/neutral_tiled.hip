@@ -76,9 +76,14 @@ constexpr int kChunkParticlesMin = 1024;
  * the idle lanes of the last facets (56: stream deck -6 %, csp -2 % against 32;
  * 56...64 are level) */
 constexpr int kStreamRefillMin = 56;
-/* facet crossings per STREAM pass (64: a csp history's whole flight of ~63 facets;
- * -1..2 % against 16) */
+/* facet crossings per STREAM pass: 64 (-1..2 % against 16), and 128 where the step's histories
+ * end their flight under the window they start in (the step before needed one stream pass: csp
+ * 400^2 with its ~63 facets per flight) -- the lanes of a wave that are through then wait for
+ * its longest flight once, not for two passes' longest; where histories change windows anyway
+ * (the stream deck: nine passes) 128 costs 4 % and 32 costs 3 (profiles/r04/experiments/
+ * stream_knobs.log).  What a history computes does not depend on it. */
 constexpr int kStreamRepeat = 64;
+constexpr int kStreamRepeatOnePass = 128;
 constexpr int kSortBlock = 256;
 /* counting sort: records one workgroup histograms and places at a time, and the
  * largest number of buckets (tiles + 1) it keeps in LDS (count + base: 64 KB);
@@ -1242,7 +1247,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
               cell_tally.m_outside = __builtin_amdgcn_ballot_w64(out_of_window);
               /* (what ends the flight is named below the loop, once; `crossed` is the trip
                * count too: every lane in the loop started with it) */
-              run = surely_next_is_facet(h) & (crossed < kStreamRepeat);
+              run = surely_next_is_facet(h) & (crossed < t.stream_repeat);
               /* (the scalar AND says whether its result is zero: one instruction and a branch) */
               if ((cell_tally.m_outside & may_migrate) != 0) {
                 asm volatile("");
@@ -1831,6 +1836,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
   t.refill_min = kStreamRefillMin;
+  /* (plan.stream_passes is what the step before needed, plus one) */
+  t.stream_repeat = (plan.stream_passes <= 2) ? kStreamRepeatOnePass : kStreamRepeat;
   const size_t lds = tiled_lds_bytes(a);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
