@@ -217,6 +217,10 @@ typedef struct {
   int exchange_rounds;   /* decomposed mesh: rounds of the particle exchange between the ranks'
                             blocks the step took (each: count, pack, exchange, append, more passes) */
   uint64_t emigrants;    /* decomposed mesh: histories THIS rank sent to other ranks' blocks */
+  uint64_t weighted_waves; /* tiled variant: waves of the collision stage that were dealt a share of
+                            the queue in proportion to what a wave is served (5 : 1 : 1 : 1 over
+                            the four waves of a SIMD; 0: equal shares -- a small queue, a partial
+                            grid) */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

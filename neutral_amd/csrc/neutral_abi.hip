@@ -101,16 +101,19 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.queue_len = nullptr;
   a.rec = nullptr;
   a.blocks_per_cu = 0;
-  a.max_blocks = 0;
   a.slot_info = nullptr;
   a.tiles_x = 0;
   a.tile_shift = 4;
   a.susp = nullptr;
   a.steal = nullptr;
-  a.steal_min = 0;
-  a.steal_delay = 0;
   a.occupancy_rows = 0;
-  a.share_weight = 1;
+  /* the launches' tuning: read from the environment and the runtime once per store -- here for
+   * a store stepped for the first time (below, where its records are imported), or on the
+   * library's first step */
+  if (!g.tuning_read) {
+    g.tuning = neutral::launch_tuning_from_env();
+    g.tuning_read = true;
+  }
   /* Default (eager) mode: the SoA arrays are current when the call returns.  One
    * export pass at the end of the step does that (5.9 ms at 1e8 particles); letting
    * every kernel that ends a history store it to the arrays itself -- eleven
@@ -129,6 +132,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         g.rec_count != a.nparticles) {
       sync_soa(); /* a previous owner's pending write-back */
       drop_records();
+      g.tuning = neutral::launch_tuning_from_env(); /* (once per store) */
       if (decomposed) {
         HIP_CHECK(neutral::launch_import_by_slot(a.p, shard->keys, g.tiled, x_off, y_off,
                                                  a.nparticles, g.stream));
@@ -184,6 +188,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       drop_records();
     }
   }
+
+  a.steal_min = g.tuning.steal_min;
+  a.steal_delay = g.tuning.steal_delay;
+  a.share_weight = g.tuning.share_weight;
+  a.weighted_share_min = g.tuning.weighted_share_min;
+  a.compute_units = g.tuning.compute_units;
+  a.max_blocks = tiled ? g.tuning.max_blocks : 0;
 
   /* Arithmetic policy of this step's kernels (neutral_device.h).  Auto: start from what
    * the last step's check found; the check of THIS step's input runs on the device ahead
@@ -541,6 +552,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     hc[1].ncollide_passes = words[kWordCollidePasses];
     hc[0].nsteals = 0;
     hc[1].nsteals = words[kWordSteals];
+    hc[0].steal_refused = 0;
+    hc[1].steal_refused = words[kWordStealsRefused];
+    hc[0].nweighted = 0;
+    hc[1].nweighted = words[kWordWeightedWaves];
     hc[0].aborted = 0;
     hc[1].aborted = (unsigned)words[kWordAborted];
   } else if (neutral::comm_nranks() > 1) {
@@ -588,6 +603,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.collide_passes = hc[0].ncollide_passes + hc[1].ncollide_passes;
   g.last.steals = hc[0].nsteals + hc[1].nsteals;
   g.last.steals_refused = hc[0].steal_refused + hc[1].steal_refused;
+  g.last.weighted_waves = hc[0].nweighted + hc[1].nweighted;
   g.last.stream_hops = tiled ? ctrl[10] : 0;
   g.last.stream_overflows = tiled ? ctrl[11] : 0;
   g.last.stream_batches = tiled ? ctrl[12] : 0;

@@ -20,7 +20,7 @@ __global__ void publish_results_kernel(const neutral::StepCounters* counters,
   }
   if (t < 8) out->check[t] = check[t];
   if (t < 16) out->ctrl[t] = ctrl ? ctrl[t] : 0u;
-  if (t < 16) out->words[t] = words ? words[t] : 0ull;
+  if (t < (unsigned)kStepWords) out->words[t] = words ? words[t] : 0ull;
 }
 
 __global__ void pack_step_words_kernel(const neutral::StepCounters* c, const unsigned long long* check,
@@ -42,6 +42,10 @@ __global__ void pack_step_words_kernel(const neutral::StepCounters* c, const uns
   w[kWordAborted] = (unsigned long long)c[0].aborted + c[1].aborted;
   w[kWordRanks] = 1ull;
   w[kWordSteals] = c[0].nsteals + c[1].nsteals;
+  w[kWordStealsRefused] = c[0].steal_refused + c[1].steal_refused;
+  w[kWordWeightedWaves] = c[0].nweighted + c[1].nweighted;
+  w[kStepWords - 2] = 0ull;
+  w[kStepWords - 1] = 0ull;
 }
 
 __global__ void add_step_tally_kernel(double* __restrict__ tally, const double* __restrict__ step,

@@ -36,7 +36,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 8 /* 8: NeutralHipStepStats grew steals_refused, stream_hops, stream_overflows; 7: NeutralHipStepStats grew steals; 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 9 /* 9: NeutralHipStepStats grew weighted_waves; 8: NeutralHipStepStats grew steals_refused, stream_hops, stream_overflows; 7: NeutralHipStepStats grew steals; 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024
@@ -90,7 +90,7 @@ struct StepResults {
   neutral::StepCounters counters[2];
   unsigned long long check[8];
   unsigned ctrl[16];
-  unsigned long long words[16];
+  unsigned long long words[20]; /* kStepWords */
 };
 
 struct State {
@@ -207,6 +207,8 @@ struct State {
   neutral::ParticleView h_export_view = {};        /* collision stage's own write-back */
   double suspended_share = -1.0;
   size_t susp_id_words = 0;
+  neutral::LaunchTuning tuning = {}; /* read once per store (neutral_kernels.h) */
+  bool tuning_read = false;
   int stream_queues = 0;   /* neutral_hip_set_stream_queues: the stream kernel's tile queues are in use */
   size_t queue_places = 0; /* ... places allocated, for how many tiles */
   int queue_tiles = 0;
@@ -229,7 +231,9 @@ enum StepWord : int {
   kWordAborted = 13,
   kWordRanks = 14,      /* 1 per rank: how many ranks the transport summed over */
   kWordSteals = 15,     /* rings the collision stage's waves took from (see StepCounters) */
-  kStepWords = 16,
+  kWordStealsRefused = 16, /* waves that found their CU list overfull and stole nothing */
+  kWordWeightedWaves = 17, /* waves of the collision stage that were dealt a weighted share */
+  kStepWords = 20,      /* (the last two spare) */
 };
 
 /* ---- neutral_abi_store.hip ---- */

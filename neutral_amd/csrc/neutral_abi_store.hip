@@ -22,7 +22,7 @@ void ensure_scratch() {
   HIP_CHECK(hipMalloc((void**)&g.d_check, 16 * sizeof(unsigned long long)));
   HIP_CHECK(hipMemset(g.d_check, 0, 16 * sizeof(unsigned long long))); /* ([8..12]: accumulators) */
   HIP_CHECK(hipMalloc((void**)&g.d_exchange, sizeof(unsigned) * 200));
-  HIP_CHECK(hipMalloc((void**)&g.d_words, sizeof(unsigned long long) * 16));
+  HIP_CHECK(hipMalloc((void**)&g.d_words, sizeof(unsigned long long) * kStepWords));
   g.tables.valid = false; /* its indexes live in the other device's scratch */
   HIP_CHECK(hipMalloc((void**)&g.d_index_fine,
                       sizeof(unsigned short) * (kMaxFineIndexBuckets + 1)));

@@ -86,6 +86,8 @@ struct StepCounters {
   unsigned long long steal_refused; /* collision stage: waves that found a CU list of more than
                                        kCuWavesMax entries and therefore stole nothing (the key
                                        read from the hardware does not name one CU: see StealWork) */
+  unsigned long long nweighted; /* collision stage: waves that were dealt a share in proportion to
+                                   what a wave is served (SolveArgs::share_weight) */
 };
 
 /* Device workspace of the collision stage's work stealing (neutral_kernels.hip): the control
@@ -174,6 +176,8 @@ struct SolveArgs {
   int share_weight;           /* collision stage: how many times the others' share of the queue
                                  the waves of the launch's first row of workgroups start with (the
                                  oldest wave of a SIMD is served first; 1: equal shares) */
+  int weighted_share_min;     /* ... from this many histories per wave on (equal shares below) */
+  int compute_units;          /* CUs of the device the launch goes to (read once per store) */
   int export_skip_long_dead;  /* the arrays were current as the step began: particles dead
                                  since before it are left alone by the write-back pass */
   /* [device] the SoA store's array pointers, when the collision stage writes the final state
@@ -274,6 +278,20 @@ struct TiledArgs {
   int nsort;               /* buckets of the counting sort: ntiles * reach_classes (+ the dead) */
   int max_chunks;
 };
+
+/* What the launches of a particle store are tuned by: constants of the kernels that tests and
+ * A/B runs override from the environment, and the device's CU count.  Read ONCE per store (when
+ * its records are imported), not per launch: three getenv and two runtime queries per collision
+ * stage were test plumbing in the hot launch path. */
+struct LaunchTuning {
+  int steal_min;          /* NEUTRAL_STEAL_MIN (default kStealMin) */
+  int share_weight;       /* NEUTRAL_SHARE_WEIGHT (default kOldestWeight) */
+  int weighted_share_min; /* NEUTRAL_WEIGHTED_SHARE_MIN (default kWeightedShareMin) */
+  int steal_delay;        /* NEUTRAL_STEAL_DELAY (default 0) */
+  int max_blocks;         /* NEUTRAL_K2_MAX_BLOCKS (default 0: no cap) */
+  int compute_units;
+};
+LaunchTuning launch_tuning_from_env();
 
 /* spatial domain decomposition: px x py ranks, uniform blocks of bx x by cells (the
  * last ones may be smaller); rank r owns block (r % px, r / px) */

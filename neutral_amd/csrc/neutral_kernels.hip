@@ -537,7 +537,7 @@ void history_regroup_kernel(SolveArgs a) {
    * histories per wave, runs 2 % slower weighted, the full size 1 % faster:
    * profiles/r04/experiments/share_weight_ab.log) */
   const bool weighted = pooled && a.occupancy_rows == 4 && block_count == (int)gridDim.x && (nwaves % 16) == 0 &&
-                        a.share_weight > 1 && (long long)nwork >= (long long)nwaves * kWeightedShareMin;
+                        a.share_weight > 1 && (long long)nwork >= (long long)nwaves * a.weighted_share_min;
   const int oldest_weight = weighted ? a.share_weight : 1;
   const int sum_weight = oldest_weight + 3;
   const int nvirtual = weighted ? (nwaves / 4) * sum_weight : nwaves;
@@ -575,6 +575,7 @@ void history_regroup_kernel(SolveArgs a) {
   /* the ring's control word is a.steal->ring_ctl[gw] (StealWork); these are the owner's own view */
   unsigned w_steals = 0;
   unsigned w_steal_refused = 0;
+  const unsigned w_weighted = (weighted && my_ring.share > 0) ? 1u : 0u;
   int ring_tail = 0;      /* ring position the next history handed back goes to (head + waiting) */
   int ring_count = share; /* histories waiting in the ring, as last seen (a CU-mate may have taken some) */
   int slice = 0;
@@ -602,9 +603,12 @@ void history_regroup_kernel(SolveArgs a) {
     /* (small shares -- a hundred histories per wave, the 8-GPU share of csp -- are better left
      * alone: what a thief takes there it runs in half-empty passes that the SIMD issues ahead
      * of its younger CU-mates' full ones; 48.5 against 46.5 ms per 10 steps) */
+    /* (asked of the EQUAL share: with weighted shares the waves of rows 1..3 own a fifth of a
+     * row-0 ring, and three quarters of the waves would never steal although the row-0 rings of
+     * their CU hold hundreds) */
     const unsigned steal_min = (unsigned)a.steal_min;
-    if (!pooled || steal_min == 0 || (unsigned)share < 2u * steal_min) {
-      return false;
+    if (!pooled || steal_min == 0 || (unsigned)(nwork / nwaves) < 2u * steal_min || share == 0) {
+      return false; /* (share == 0: no ring of its own to copy what it takes into) */
     }
     StealWork* const sw = cold_args().steal;
     if (__hip_atomic_load(&sw->overfull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -676,8 +680,9 @@ void history_regroup_kernel(SolveArgs a) {
       if (!wave_uniform(won)) {
         continue; /* (its owner or another thief was quicker: look again) */
       }
-      /* every take: nothing stale in this CU's L1 of what the wave reads next, whichever CU
-       * its owner ran on (the records themselves are read with loads that bypass the L1) */
+      /* every take: nothing stale in this CU's L1 of what the wave reads next -- ring words and,
+       * at the refill that follows, the records with plain loads -- whichever CU its owner ran
+       * on (the owner's hand-back was plain stores, drained before the control word said so) */
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       /* (nobody is still reading what was taken from THIS wave's ring earlier) */
       while (__hip_atomic_load(&sw->ring_readers[gw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -996,6 +1001,7 @@ void history_regroup_kernel(SolveArgs a) {
     if (w_requeued) atomicAdd(&a.counters->nrequeued, (unsigned long long)w_requeued);
     if (w_steals) atomicAdd(&a.counters->nsteals, (unsigned long long)w_steals);
     if (w_steal_refused) atomicAdd(&a.counters->steal_refused, (unsigned long long)w_steal_refused);
+    if (w_weighted) atomicAdd(&a.counters->nweighted, 1ull);
     if (w_collide_passes) {
       atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
     }
@@ -1271,6 +1277,33 @@ hipError_t launch_probe_division(const double* in, double* out, int* plain, int 
 
 /* ---- launchers -------------------------------------------------------------- */
 
+LaunchTuning launch_tuning_from_env() {
+  LaunchTuning t;
+  auto env_int = [](const char* name, int fallback, int lo, int hi) {
+    const char* v = getenv(name);
+    if (v && *v) {
+      const int i = atoi(v);
+      if (i >= lo && i <= hi) {
+        return i;
+      }
+    }
+    return fallback;
+  };
+  t.steal_min = env_int("NEUTRAL_STEAL_MIN", kStealMin, 0, 1 << 20);       /* (tests: small rings taken from too) */
+  t.share_weight = env_int("NEUTRAL_SHARE_WEIGHT", kOldestWeight, 1, 16);   /* (A/B and tests: 1 = equal shares) */
+  t.weighted_share_min = env_int("NEUTRAL_WEIGHTED_SHARE_MIN", kWeightedShareMin, 1, 1 << 20); /* (tests) */
+  t.steal_delay = env_int("NEUTRAL_STEAL_DELAY", 0, 0, 1 << 20);            /* (tests: a slow thief) */
+  /* (tests: a small grid makes the collision stage time-slice -- shares larger than a wave --
+   * at particle counts a CPU oracle can follow) */
+  t.max_blocks = env_int("NEUTRAL_K2_MAX_BLOCKS", 0, 0, 1 << 20);
+  int dev = 0;
+  t.compute_units = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    (void)hipDeviceGetAttribute(&t.compute_units, hipDeviceAttributeMultiprocessorCount, dev);
+  }
+  return t;
+}
+
 hipError_t launch_probe_threefry(const uint64_t* in, uint64_t* out, double* rn, int n,
                                  hipStream_t stream) {
   hipLaunchKernelGGL(probe_threefry_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0,
@@ -1313,13 +1346,9 @@ hipError_t launch_inject(const InjectArgs& a, hipStream_t stream) {
 /* blocks of kBlock threads the device keeps resident for a kernel that takes `lds`
  * bytes of dynamic LDS per block */
 template <typename K>
-static int resident_blocks(K kernel, size_t lds) {
-  int dev = 0;
-  int cus = 256;
+static int resident_blocks(K kernel, size_t lds, int compute_units) {
+  const int cus = compute_units > 0 ? compute_units : 256;
   int per_cu = 2;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
   /* registers decide (3 waves per SIMD: section above); the occupancy query is asked
    * without the dynamic LDS, which it prices against 64 KB per CU where gfx950 has
    * 160 KB, and the LDS bound is applied by hand */
@@ -1360,33 +1389,22 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       /* (the indexes of two distinct large tables can exceed the 64 KB default) */
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
-      int grid = resident_blocks(kernel, lds);
+      int grid = resident_blocks(kernel, lds, a.compute_units);
       k.occupancy_rows = 0;
+      const int cus = a.compute_units > 0 ? a.compute_units : 256;
       if (a.blocks_per_cu == -1) {
         /* the kernel picks its own occupancy among the rows of #CUs workgroups that are
          * resident together; otherwise everybody works */
-        int cus = 256;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        }
         const int rows = grid / cus;
         const bool fits = (rows >= 2) && (grid == rows * cus) && (want_blocks >= grid) &&
                           !(a.max_blocks > 0 && a.max_blocks < grid);
         k.occupancy_rows = fits ? rows : 0;
         k.blocks_per_cu = 0;
       }
-      if (a.blocks_per_cu > 0) {
+      if (a.blocks_per_cu > 0 && a.blocks_per_cu * cus < grid) {
         /* the caller knows how little work there is: fewer resident waves per
          * SIMD shorten every history's serial chain (see launch_solve_tiled) */
-        int cus = 256;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        }
-        if (a.blocks_per_cu * cus < grid) {
-          grid = a.blocks_per_cu * cus;
-        }
+        grid = a.blocks_per_cu * cus;
       }
       if (grid > want_blocks) {
         grid = want_blocks;
@@ -1394,27 +1412,8 @@ hipError_t launch_solve(const SolveArgs& a, int variant, hipStream_t stream) {
       if (a.max_blocks > 0 && grid > a.max_blocks) {
         grid = a.max_blocks;
       }
-      k.steal_min = kStealMin;
-      {
-        const char* force = getenv("NEUTRAL_STEAL_MIN"); /* (tests: small rings taken from too) */
-        if (force && atoi(force) >= 0) {
-          k.steal_min = atoi(force);
-        }
-      }
-      k.share_weight = kOldestWeight;
-      {
-        const char* w = getenv("NEUTRAL_SHARE_WEIGHT"); /* (A/B and tests: 1 = equal shares) */
-        if (w && atoi(w) >= 1 && atoi(w) <= 16) {
-          k.share_weight = atoi(w);
-        }
-      }
-      k.steal_delay = 0;
-      {
-        const char* delay = getenv("NEUTRAL_STEAL_DELAY"); /* (tests: a slow thief) */
-        if (delay && atoi(delay) > 0) {
-          k.steal_delay = atoi(delay);
-        }
-      }
+      /* (k.steal_min, share_weight, weighted_share_min, steal_delay: the store's LaunchTuning,
+       * filled in by the caller -- read from the environment once per store, not here) */
       if (a.queue && k.steal) {
         /* rings' control words zero, CU lists empty (every entry invalid), nobody reading */
         hipLaunchKernelGGL(steal_reset_kernel, dim3((kCuSlots * kCuWavesMax + 255) / 256), dim3(256), 0,

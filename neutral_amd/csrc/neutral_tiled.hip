@@ -1128,6 +1128,8 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
              * a record of this store -- is reported and dropped, never dereferenced) */
             if (src >= (unsigned)a.nparticles) {
               atomicAdd(&a.counters->aborted, 1u);
+              ended = true; /* (it leaves the launch's count of histories in flight: the other
+                             * workgroups do not poll for it until they give up) */
             } else {
             pid = fresh ? mine : (int)src; /* this history's slot in rec_out */
             bool bad_load = false;
@@ -1155,6 +1157,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             }
             if (bad_load) {
               atomicAdd(&a.counters->aborted, 1u);
+              ended = true; /* (as above) */
             } else {
             if (fresh) {
               prologue<kSameTables, kChecked>(h, a, ix);
@@ -1829,11 +1832,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
     t.sort_end = a.nparticles; /* (no graveyard: slots come and go within a step) */
     t.mirror_end = a.nparticles;
   }
-  int dev = 0;
-  int cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  }
+  const int cus = a.compute_units > 0 ? a.compute_units : 256; /* (the store's LaunchTuning) */
   t.chunk_particles = tiled_chunk_particles(a.nparticles, cus);
   t.refill_min = kStreamRefillMin;
   /* (plan.stream_passes is what the step before needed, plus one) */
@@ -1881,12 +1880,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   SolveArgs c = a;
   c.blocks_per_cu = plan.blocks_per_cu;
-  {
-    /* test knob: a small grid makes the collision stage time-slice (shares larger
-     * than a wave) at particle counts a CPU oracle can follow */
-    const char* max_blocks = getenv("NEUTRAL_K2_MAX_BLOCKS");
-    c.max_blocks = max_blocks ? atoi(max_blocks) : 0;
-  }
+  /* (c.max_blocks: the store's LaunchTuning, NEUTRAL_K2_MAX_BLOCKS -- a small grid makes the
+   * collision stage time-slice at particle counts a CPU oracle can follow) */
   c.counters = a.counters + 1;
   c.queue = t.collide_queue;
   c.queue_len = &t.ctrl[kCtrlCollideCount];

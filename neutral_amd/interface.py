@@ -73,7 +73,8 @@ class StepStats(C.Structure):
                 ("stream_hops", C.c_uint64), ("stream_overflows", C.c_uint64),
                 ("stream_batches", C.c_uint64), ("stream_idle_polls", C.c_uint64),
                 ("local_nprocessed", C.c_uint64), ("exchange_ms", C.c_double),
-                ("exchange_rounds", C.c_int), ("emigrants", C.c_uint64)]
+                ("exchange_rounds", C.c_int), ("emigrants", C.c_uint64),
+                ("weighted_waves", C.c_uint64)]
 
 
 # every symbol include/neutral_hip.h declares

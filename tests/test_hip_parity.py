@@ -468,6 +468,10 @@ def test_reference_known_answers_default_decks(iface, make_problem, cs, name, va
     assert "PASSED validation." in out, out
     total = float(sim.tally_host().sum())
     assert abs(total - decks.KNOWN_ANSWERS[name]) / decks.KNOWN_ANSWERS[name] < 1e-3
+    if name == "stream":
+        import closed_form  # (the deck as shipped against its closed form: 1e-12)
+        exact = closed_form.stream_deck_tally(*cs)
+        assert abs(total - exact) / exact < 1e-12
     sim.close()
 
 
@@ -512,20 +516,42 @@ def test_csp_400_ten_steps_matches_recorded_omp3(iface, make_problem, cs, pins, 
     sim.close()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_stream_deck_closed_form(iface, make_problem, cs, variant):
+    """The stream deck against its closed form (tests/closed_form.py: reference-held constants,
+    the shipped table, omp3/neutral.c:117,474-495 -- no oracle in between): the global tally is
+    speed * dt * sigma_t * BARNS * heating * n per timestep whatever the mesh and the particle
+    count.  HIP path at 1e-12 (problems/neutral.tests:2 holds 1e-3), every variant, two steps."""
+    import closed_form
+    prob = make_problem("stream", nx=200, nparticles=200000, iterations=2)
+    sim = iface.Simulation(prob, *cs, variant=variant)
+    sim.inject()
+    for tt in (1, 2):
+        s = sim.step(tt)
+        assert s.collisions == 0 and s.nprocessed == 200000
+        exact = closed_form.stream_deck_tally(*cs, iterations=tt)
+        assert abs(float(sim.tally_host().sum()) - exact) / exact < 1e-12
+    sim.close()
+
+
 def test_stream_tally_is_intensive_in_particle_count(iface, make_problem, cs):
     """stream: uniform near-vacuum, no collisions, so the global tally per source
     particle is independent of N -- checked at 1e7 particles
-    (BASELINE config 2) against 1e5."""
-    totals = []
+    (BASELINE config 2) and at 1e5 against the deck's closed form (tests/closed_form.py) at
+    1e-12, and against the shipped known answer at the reference's own 1e-3."""
+    import closed_form
+    from neutral_amd import decks
+    exact = closed_form.stream_deck_tally(*cs)
     for n in (100000, 10000000):
         prob = make_problem("stream", nx=400, nparticles=n, iterations=1)
         sim = iface.Simulation(prob, *cs, variant=2)
         sim.inject()
         s = sim.step(1)
         assert s.collisions == 0 and s.nprocessed == n
-        totals.append(float(sim.tally_host().sum()))
+        total = float(sim.tally_host().sum())
         sim.close()
-    assert totals[0] == pytest.approx(totals[1], rel=2e-3)
+        assert abs(total - exact) / exact < 1e-12, (n, total, exact)
+        assert abs(total - decks.KNOWN_ANSWERS["stream"]) / decks.KNOWN_ANSWERS["stream"] < 1e-3
 
 
 @pytest.mark.parametrize("deck,nx,n,dt", [("csp", 100, 50000, 1.0e-6), ("split", 200, 60000, 5.0e-7),

@@ -22,6 +22,7 @@ import os
 import numpy as np
 import pytest
 
+import closed_form
 import oracle_binding as ob
 from neutral_amd import decks
 
@@ -126,6 +127,24 @@ def test_recorded_not_reproducible_here__omp3_runs(pins, make_problem, cs, i):
     assert run.tally_sum() == pytest.approx(r["tally"], rel=1e-13)
 
 
+@pytest.mark.parametrize("nx,n,its", [(100, 20000, 1), (37, 5000, 3)])
+def test_reference_held__stream_deck_closed_form(make_problem, cs, nx, n, its):
+    """The stream deck has a closed form from reference-held inputs alone (tests/closed_form.py:
+    the constants of neutral_data.h:17-24, the shipped .cs table, omp3/neutral.c:117,474-495 --
+    nothing of the restatement): speed * dt * sigma_t * BARNS * heating * n per timestep, whatever
+    the mesh and the particle count.  The oracle reproduces it to 1e-12; the reference's own
+    known answer (problems/neutral.tests:2, held at 1e-3) agrees with it to 1e-6."""
+    expected = closed_form.stream_deck_tally(*cs, iterations=its)
+    assert expected == pytest.approx(5.7600599264841e-24 * its, rel=1e-12)
+    assert abs(decks.KNOWN_ANSWERS["stream"] - closed_form.stream_deck_tally(*cs)) < \
+        1e-6 * decks.KNOWN_ANSWERS["stream"]
+    run, facets, collisions, _ = _run_oracle(make_problem, cs, "stream", nx, n, its)
+    assert collisions == 0 and facets > 0
+    rel = abs(run.tally_sum() - expected) / expected
+    print(f"stream {nx}^2 / {n} x {its}: oracle {run.tally_sum():.15e} closed form {expected:.15e} rel {rel:.2e}")
+    assert rel < 1e-12
+
+
 _default_deck_runs = {}
 
 
@@ -157,6 +176,11 @@ def test_reference_held__known_answers_default_decks(make_problem, cs, name):
     print(f"{name} as shipped: facets={facets} collisions={collisions} tally={tally:.15e} "
           f"expected={expected:.12e} rel={abs(tally - expected) / expected:.2e}")
     assert abs(tally - expected) / expected < decks.VALIDATE_TOLERANCE
+    if name == "stream":
+        # ... and, at the deck's own size, the closed form (tests/closed_form.py) at 1e-12
+        exact = closed_form.stream_deck_tally(*cs)
+        print(f"stream as shipped against the closed form: rel={abs(tally - exact) / exact:.2e}")
+        assert abs(tally - exact) / exact < 1e-12
 
 
 @pytest.mark.parametrize("name", DEFAULT_DECKS)

@@ -147,6 +147,41 @@ def test_histories_taken_over_by_another_wave(iface, make_problem, cs, monkeypat
     assert sum(s.steals for s in alone[3]) == 0
 
 
+@pytest.mark.parametrize("deck,nx,n,dt,steps,weight", [
+    ("split", 200, 1000000, 5.0e-7, 2, 5),    # 244 histories per wave: 610 / 122 / 122 / 122
+    ("scatter", 200, 800000, None, 1, 3),     # 195 per wave, a last round that is partial
+    ("scatter", 128, 530001, None, 1, 8),     # the smallest full grid: 129 per wave, 8 : 1 : 1 : 1
+])
+def test_weighted_shares_at_test_size(iface, make_problem, cs, monkeypatch, deck, nx, n, dt, steps,
+                                      weight):
+    """Shares in proportion to what a wave is served (history_regroup_kernel: ring_map /
+    ring_index, 5 : 1 : 1 : 1 over the four waves of a SIMD) are dealt by default only from 256
+    histories per wave on -- 1e7-particle runs, out of the default suite's reach (round-4 advisor
+    finding).  NEUTRAL_WEIGHTED_SHARE_MIN lowers that bar, NEUTRAL_STEAL_MIN=1 lets thieves use the
+    victims' weighted maps on rings of any size: a full grid of 4 096 waves, partial last rounds,
+    wrap-arounds of the small rings -- same bits as the over-particle kernel, no history lost or
+    run twice (the event counts say so), and the stage reports that the weighted map was the
+    one in use."""
+    kw = dict(nx=nx, nparticles=n, iterations=steps)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    want = _run(iface, prob, cs, 0, steps)
+    monkeypatch.setenv("NEUTRAL_WEIGHTED_SHARE_MIN", "8")
+    monkeypatch.setenv("NEUTRAL_SHARE_WEIGHT", str(weight))
+    monkeypatch.setenv("NEUTRAL_STEAL_MIN", "1")
+    got = _run(iface, prob, cs, 2, steps)
+    _same(want, got)
+    assert max(s.weighted_waves for s in got[3]) >= 4000, [s.weighted_waves for s in got[3]]
+    assert sum(s.steals for s in got[3]) > 100
+    assert sum(s.requeued for s in got[3]) > 0
+    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3])
+    monkeypatch.setenv("NEUTRAL_SHARE_WEIGHT", "1")
+    equal = _run(iface, prob, cs, 2, steps)
+    _same(want, equal)
+    assert all(s.weighted_waves == 0 for s in equal[3])
+
+
 def test_a_slow_thief_is_waited_for(iface, make_problem, cs, monkeypatch):
     """The owner of a ring does not store into it while a thief is still copying what it took
     (round-3 advisor finding: only timing kept the two apart).  NEUTRAL_STEAL_DELAY makes every
