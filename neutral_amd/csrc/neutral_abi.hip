@@ -105,6 +105,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.tiles_x = 0;
   a.tile_shift = 4;
   a.susp = nullptr;
+  a.micro = nullptr;
   a.steal = nullptr;
   a.occupancy_rows = 0;
   /* the launches' tuning: read from the environment and the runtime once per store -- here for
@@ -138,7 +139,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
                                                  a.nparticles, g.stream));
       } else {
         HIP_CHECK(neutral::launch_import_records(a.p, g.tiled.rec_in, g.tiled.info_in,
-                                                 g.tiled.slot_of_id, g.tiled.tiles_x,
+                                                 g.tiled.slot_of_id, g.tiled.id_in, g.tiled.tiles_x,
                                                  g.tiled.tile_shift, x_off, y_off, a.nparticles,
                                                  g.stream));
       }
@@ -301,6 +302,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       }
     }
 
+    if (tiled && neutral::tiled_uses_carried(a, g.tiled) && !g.carried_valid) {
+      /* the stream kernel starts histories from the cross section carried with each record:
+       * looked up here for a store just imported, or after the table view was rebuilt (an
+       * attempt that is turned down for a stale view comes back through here) */
+      HIP_CHECK(neutral::launch_refresh_micro(a, g.tiled, g.stream));
+      g.carried_valid = true;
+    }
     HIP_CHECK(hipMemsetAsync(g.d_counters, 0, 2 * sizeof(neutral::StepCounters), g.stream));
     if (tiled) {
       /* (the pipeline's control words are set by its own kernels -- unless there is
@@ -521,6 +529,12 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     unsigned* swap_id = t.id_in;
     t.id_in = t.id_out;
     t.id_out = swap_id;
+    double* swap_micro = t.micro_in;
+    t.micro_in = t.micro_out;
+    t.micro_out = swap_micro;
+    if (!t.carried) {
+      g.carried_valid = false; /* (a step that looked up and drew itself kept none of it) */
+    }
     g.plan_passes = (int)ctrl[5] > 0 ? (int)ctrl[5] : 1;
     g.soa_valid = !g.lazy_export; /* eager: exported above (or by the kernels) */
     g.suspended_share = (double)queue_total /

@@ -145,6 +145,7 @@ void sync_soa() {
  * layout changes): the next tiled step imports it again. */
 void drop_records() {
   g.rec_valid = false;
+  g.carried_valid = false; /* (TiledArgs::micro_in belongs to the records) */
   g.suspended_share = -1.0;
   g.free_count = 0; /* (slots emigrants left are holes of the records, not of the arrays) */
   g.plan_passes = 0;
@@ -175,7 +176,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   if (grow) {
     void* old[] = {t.order,  t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor, t.rec_in,
                    t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out,
-                   t.slot_of_id, t.tile_uniform};
+                   t.slot_of_id, t.tile_uniform, t.micro_in, t.micro_out, t.mlog_in};
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -193,6 +194,9 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     HIP_CHECK(hipMalloc((void**)&t.id_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.id_out, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.slot_of_id, sizeof(unsigned) * n));
+    HIP_CHECK(hipMalloc((void**)&t.micro_in, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void**)&t.micro_out, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void**)&t.mlog_in, sizeof(double) * n));
     HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
     HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));
@@ -327,6 +331,7 @@ void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCros
                          v.variant == g.variant;
   if (!same_args || rebuild) {
     v.valid = false;
+    g.carried_valid = false; /* (the records' carried cross sections were looked up in other tables) */
     v.keys_s = cs_s->keys;
     v.values_s = cs_s->values;
     v.n_s = cs_s->nentries;

@@ -726,6 +726,71 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
   refresh_deposition_terms<kSameTables, kChecked>(h);
 }
 
+/* ---- the same two starts with what a history's start does NOT depend on taken out ----------
+ * (stream kernel, identical tables, one rank's whole mesh).  Of the prologue's inputs
+ * (omp3/neutral.c:103-131) two are known before the history's lane is: the microscopic cross
+ * section -- a function of the energy, which a history keeps from the end of one timestep to
+ * the start of the next and through every facet of its flight -- and the first sample of the
+ * step, -log(rn0), a function of the particle id and the timestep alone.  The first travels with
+ * the record (TiledArgs::micro_in / micro_out: written by whoever last changed the energy), the
+ * second is worked out by the counting sort's placement pass, which touches every live record
+ * once per step and waits on atomics while it does (TiledArgs::mlog_in).  What is left of a
+ * start is a chain of three dependent loads (sorted order -> record -> density) instead of
+ * seven (+ index, 1-3 table probes, the bracket's keys and values), and a third of the vector
+ * instructions: the refill was a quarter of the stream stage's wave time
+ * (profiles/r04/experiments/fast_facets.log).  Same operations on the same operands as
+ * prologue() / resume(): same bits.
+ * density_known (wave-uniform): the history starts under a tally window whose cells all hold
+ * one density (TiledArgs::tile_uniform, checked on the device this step) -- the caller has it in
+ * a scalar register, and the chain is order -> record. */
+template <bool kChecked>
+__device__ __forceinline__ void start_carried(History& h, const SolveArgs& a, double micro,
+                                              bool density_known, double known_density) {
+  if (density_known) {
+    h.local_density = known_density;
+  } else {
+    h.local_density = a.density[(h.celly - a.y_off + a.pad) * (a.nx + 2 * a.pad) +
+                                (h.cellx - a.x_off + a.pad)];
+  }
+  h.micro_s = micro;
+  h.micro_a = micro; /* identical tables: the same bits (lookup_cs) */
+  macroscopic_from_density<kChecked>(h);
+  h.speed = speed_of<kChecked>(h.energy);
+  h.energy_deposition = 0.0;
+  h.track_length = 0.0;
+  h.nevents = 0;
+  refresh_direction(h);
+  refresh_deposition_terms<true, kChecked>(h);
+}
+
+/* omp3/neutral.c:103-131 with the lookup and the draw carried in: minus_log_rn0 = -log(rn0) of
+ * generate_random_numbers(pid_base + id, master_key, 0) (draw_first_flight below) */
+template <bool kChecked>
+__device__ __forceinline__ void prologue_carried(History& h, const SolveArgs& a, double micro,
+                                                 double minus_log_rn0, bool density_known,
+                                                 double known_density) {
+  start_carried<kChecked>(h, a, micro, density_known, known_density);
+  h.counter = 1; /* (the draw of :127-131 has been made) */
+  h.dt_to_census = a.dt;
+  h.mfp_to_collision = minus_log_rn0 / h.macro_s;
+}
+
+/* resume() with the lookup carried in (dt_to_census, mfp_to_collision and the counter come
+ * from the record) */
+template <bool kChecked>
+__device__ __forceinline__ void resume_carried(History& h, const SolveArgs& a, double micro,
+                                               bool density_known, double known_density) {
+  start_carried<kChecked>(h, a, micro, density_known, known_density);
+}
+
+/* -log(rn0) of a history's first draw of the timestep (omp3/neutral.c:127-131, counter 0).  A
+ * sample lies in [2^-65, 1]: log_core() is what both arithmetic policies evaluate there. */
+__device__ __forceinline__ double draw_first_flight(uint64_t pkey, uint64_t master_key) {
+  double rn0, rn1;
+  generate_random_numbers(pkey, master_key, 0, rn0, rn1);
+  return -log_core(rn0, 0);
+}
+
 /* the four mesh edges around a cell (omp3/neutral.c:438-447 reads them per event) */
 struct CellEdges {
   double x_lo, x_hi, y_lo, y_hi;

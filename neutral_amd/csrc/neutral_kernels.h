@@ -166,6 +166,8 @@ struct SolveArgs {
   int tile_shift;            /* log2 of the tile edge in cells (4..7) */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
   double* susp_track;        /* ... their pending weight * path length (scalar flux only) */
+  double* micro;             /* per-record microscopic cross section the collision stage leaves for
+                                the next timestep's start (TiledArgs::micro_out; null: not kept) */
   int steal_min;              /* collision stage: waiting histories a ring must hold to be taken
                                  from by a CU-mate (0: no stealing; NEUTRAL_STEAL_MIN) */
   StealWork* steal;           /* [device] rings' control words and CU lists (null: no stealing) */
@@ -209,6 +211,22 @@ struct TiledArgs {
   unsigned* id_out;        /* that a reader takes 4 bytes per record, not a 64-byte sector) */
   unsigned* slot_of_id;    /* nparticles: where particle id's record is -- what the write-back
                               goes by */
+  /* What a history's start does not depend on, kept per record slot so that the stream kernel
+   * starts from it (neutral_history.h: prologue_carried; identical tables, one rank's whole
+   * mesh, no tile queues -- the other instantiations look up and draw as before):
+   *   micro_in / micro_out  the microscopic cross section of the record's energy, next to
+   *                         rec_in / rec_out: written by whoever places the record (pass 0 of
+   *                         the stream kernel copies it across) or changes its energy (the
+   *                         collision stage, where it ends a history); valid for every live
+   *                         slot of rec_in whenever carried_valid says so -- the host runs
+   *                         refresh_micro_kernel first when it does not (a store just imported,
+   *                         a table view just rebuilt);
+   *   mlog_in               -log(rn0) of this timestep's first draw, per slot of rec_in: the
+   *                         counting sort's placement pass (pass 0) works it out from id_in. */
+  double* micro_in;
+  double* micro_out;
+  double* mlog_in;
+  int carried;             /* 1: this step's stream kernel starts from them (set per step) */
   /* The graveyard.  Records [sort_end, nparticles) belong to particles that were dead when
    * the LAST step began: they keep their slots for good, in both record buffers, and take
    * no part in the sort.  The dead of this step's sort are carried over to [first_inactive,
@@ -342,11 +360,16 @@ hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const
 
 
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
-size_t tiled_lds_bytes(const SolveArgs& a);
+size_t tiled_lds_bytes(const SolveArgs& a, bool carried = false);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
-                                 int n, hipStream_t stream);
+                                 unsigned* slot_of_id, unsigned* ids, int tiles_x, int tile_shift,
+                                 int x_off, int y_off, int n, hipStream_t stream);
+/* micro_in[slot] for every live record of t.rec_in, by plain bisection of the scatter table (no
+ * index: independent of the cached view) -- after an import, after the table view was rebuilt */
+hipError_t launch_refresh_micro(const SolveArgs& a, const TiledArgs& t, hipStream_t stream);
+/* does this step's stream kernel start histories from the carried values? */
+bool tiled_uses_carried(const SolveArgs& a, const TiledArgs& t);
 /* slot_of_id: where each id's record is (TiledArgs::slot_of_id) */
 /* Records in slots from a boundary on belong to particles whose final state the arrays hold
  * already and are left alone (the random access to them is what the pass is bound by):

@@ -381,13 +381,18 @@ __device__ __forceinline__ SolveArgs cold_args() {
 }
 
 /* final state of a history: into the SoA store, or into its record in queue mode */
-template <bool kQueue>
+template <bool kQueue, bool kCarriesMicro = false>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
     store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
+    if (kCarriesMicro && a.micro) {
+      /* what the next timestep's start takes from the record's slot instead of looking it up
+       * (TiledArgs::micro_out): the cross section of the energy the history ends with */
+      a.micro[pid] = h.micro_s;
+    }
     if (a.export_view) {
       /* the interface's arrays get the final state here (the write-back of the histories that
        * never came to this stage runs beside it: TiledArgs::susp_ids) -- eleven scattered
@@ -883,6 +888,7 @@ void history_regroup_kernel(SolveArgs a) {
             ncollisions++;
           }
           if (collide<kSameTables, kChecked>(h, a, ix, tally, [&](const History& d) {
+                /* (the dead start no further timestep: nothing carried for them) */
                 put_back<kQueue>(d, NEUTRAL_COLD_ARGS(a), pid);
               })) {
             want = kWantRefill;
@@ -989,7 +995,7 @@ void history_regroup_kernel(SolveArgs a) {
             ncensus++;
             census<kChecked>(h, c, tally);
           }
-          put_back<kQueue>(h, c, pid); /* kEvEnd: the loop at :134 simply exits */
+          put_back<kQueue, kSameTables>(h, c, pid); /* kEvEnd: the loop at :134 simply exits */
           want = kWantRefill;
         }
       }

@@ -84,6 +84,13 @@ constexpr int kStreamRefillMin = 56;
  * stream_knobs.log).  What a history computes does not depend on it. */
 constexpr int kStreamRepeat = 64;
 constexpr int kStreamRepeatOnePass = 128;
+/* -DNEUTRAL_NO_CARRIED_START: the A/B build in which every instantiation looks up and draws in
+ * the stream kernel's refill (tiled_uses_carried) */
+#ifdef NEUTRAL_NO_CARRIED_START
+constexpr bool kCarriedStart = false;
+#else
+constexpr bool kCarriedStart = true;
+#endif
 constexpr int kSortBlock = 256;
 /* counting sort: records one workgroup histograms and places at a time, and the
  * largest number of buckets (tiles + 1) it keeps in LDS (count + base: 64 KB);
@@ -278,11 +285,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
  * reservation with LDS atomics.  (The order inside a tile is whatever the atomics
  * make it: nothing depends on it -- histories are independent and the tally is a
  * sum.) */
+/* Pass 0 also makes every live history's first draw of the timestep (TiledArgs::mlog_in):
+ * Threefry and the logarithm, 250 vector instructions per record, in a kernel that otherwise
+ * waits on atomics -- instead of at the head of the stream kernel's refill chain. */
+__device__ __forceinline__ void draw_for_slot(const SolveArgs& a, const TiledArgs& t, long long slot) {
+  t.mlog_in[slot] = draw_first_flight(a.pid_base + (uint64_t)t.id_in[slot], a.master_key);
+}
+
 __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, TiledArgs t) {
   extern __shared__ unsigned s_bins[]; /* count/rank [nbins], base [nbins] */
   if (pass_is_empty(t) || (t.pass > 0 && step_is_broken(a))) {
     return;
   }
+  const bool draws = t.pass == 0 && t.carried != 0;
   const int nbins = t.nsort + 1;
   const bool in_lds = nbins <= kSortLdsBins;
   unsigned* s_rank = s_bins;
@@ -313,6 +328,9 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
         const unsigned pos = is_dead ? dead_base + (unsigned)lane_rank(m_dead)
                                      : atomicAdd(&t.tile_cursor[bucket[k]], 1u);
         t.order[pos] = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+        if (draws && !is_dead) {
+          draw_for_slot(a, t, base + (long long)k * kSortBlock + threadIdx.x);
+        }
       }
     }
     return;
@@ -341,6 +359,15 @@ __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, T
     if (bucket[k] != kNoBucket) {
       const unsigned pos = s_base[bucket[k]] + atomicAdd(&s_rank[bucket[k]], 1u);
       t.order[pos] = (unsigned)(base + (long long)k * kSortBlock + threadIdx.x);
+    }
+  }
+  if (draws) {
+    /* (a loop, not sixteen unrolled copies of Threefry: the kernel's code stays small) */
+#pragma unroll 1
+    for (int k = 0; k < kSortItems; ++k) {
+      if (bucket[k] != kNoBucket && bucket[k] != (unsigned)t.nsort) {
+        draw_for_slot(a, t, base + (long long)k * kSortBlock + threadIdx.x);
+      }
     }
   }
 }
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(kSortBlock) void collect_suspended_kernel(SolveArgs
 __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView p, ParticleRec* rec,
                                                                     unsigned* info,
                                                                     unsigned* slot_of_id,
-                                                                    int tiles_x,
+                                                                    unsigned* ids, int tiles_x,
                                                                     int tile_shift, int x_off,
                                                                     int y_off, int n) {
   const int i = blockIdx.x * kSortBlock + threadIdx.x;
@@ -459,9 +486,29 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
     r.dead = p.dead[i];
     rec[i] = r;
     slot_of_id[i] = (unsigned)i;
+    ids[i] = (unsigned)i;
     info[i] = slot_summary(r.dead ? kRecDead : kRecIdle, r.cellx - x_off, r.celly - y_off, tiles_x,
                            tile_shift);
   }
+}
+
+/* micro_in[slot] for every live record of rec_in (TiledArgs::micro_in): what the stream kernel's
+ * carried start takes for granted, made good after an import or a rebuilt table view.  Plain
+ * bisection -- the same unique bracket as the indexed search, hence the same value -- so that
+ * nothing here depends on the cached indexes. */
+__global__ __launch_bounds__(kSortBlock) void refresh_micro_kernel(SolveArgs a, TiledArgs t) {
+  const long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x;
+  if (i >= t.sort_end) {
+    return;
+  }
+  const int state = summary_state(t.info_in[i]);
+  if (state == kRecDead || state == kRecGone) {
+    return;
+  }
+  const double energy = t.rec_in[i].energy;
+  const int ind = cs_bracket(a.scatter_keys, a.scatter_n, energy);
+  t.micro_in[i] = a.checked ? cs_interpolate<true>(a.scatter_keys, a.scatter_values, ind, energy)
+                            : cs_interpolate<false>(a.scatter_keys, a.scatter_values, ind, energy);
 }
 
 /* records -> SoA store.  A direct scatter (each record to the eleven arrays at its
@@ -741,13 +788,15 @@ __device__ __forceinline__ void flush_window(const SolveArgs& a, double* window,
 
 /* bytes of the stream kernel's dynamic LDS in front of its control words: the window(s),
  * the staged cs index(es), rounded up to 16 */
-template <bool kSameTables>
+/* (kWithIndex = false: an instantiation that starts histories from carried values looks
+ * nothing up and stages no index) */
+template <bool kSameTables, bool kWithIndex = true>
 __host__ __device__ __forceinline__ size_t stream_lds_payload_bytes(const SolveArgs& a, int window_cells) {
   size_t lds = sizeof(double) * (size_t)window_cells;
-  if (a.scatter_index) {
+  if (kWithIndex && a.scatter_index) {
     lds += sizeof(unsigned short) * (size_t)(a.scatter_index_n + 1);
   }
-  if (!kSameTables && a.absorb_index) {
+  if (kWithIndex && !kSameTables && a.absorb_index) {
     lds += sizeof(unsigned short) * (size_t)(a.absorb_index_n + 1);
   }
   return (lds + 15) & ~(size_t)15;
@@ -815,6 +864,9 @@ template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked, bool kQueue
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
   constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
   constexpr int kWindows = kFlux ? 2 : 1;
+  /* histories start from carried values (neutral_history.h: prologue_carried; the launcher sees
+   * to it that they are valid: tiled_uses_carried): no lookup, no draw, no index in LDS */
+  constexpr bool kCarried = kCarriedStart && kSameTables && !kDomain && !kQueues;
   extern __shared__ double lds_raw[];
   constexpr int kWindowDoubles = kW * (kW + kWindowRowPad); /* a window in LDS: kW rows (neutral_history.h) */
   double* window = lds_raw;                                             /* kWindows of them */
@@ -823,7 +875,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
    * LDS in front of them: the window then starts at LDS address 0 and a cell's address is a
    * shift and a shift-add, without the add of the static variables' size (one vector
    * instruction per facet) */
-  int* const lds_ctl = (int*)((char*)lds_raw + stream_lds_payload_bytes<kSameTables>(a, kWindows * kWindowDoubles));
+  int* const lds_ctl = (int*)((char*)lds_raw + stream_lds_payload_bytes<kSameTables, !kCarried>(a, kWindows * kWindowDoubles));
   int& s_chunk = lds_ctl[0];
   int& s_end = lds_ctl[1];
   int& s_tile = lds_ctl[2];
@@ -840,14 +892,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   CsLookup<const unsigned short*> ix{nullptr, nullptr};
   {
     int used = 0;
-    if (a.scatter_index) {
+    if (!kCarried && a.scatter_index) {
       for (int i = threadIdx.x; i <= a.scatter_index_n; i += kStreamBlock) {
         lds_index[i] = a.scatter_index[i];
       }
       ix.scatter_index = lds_index;
       used = a.scatter_index_n + 1;
     }
-    if (!kSameTables && a.absorb_index) {
+    if (!kCarried && !kSameTables && a.absorb_index) {
       for (int i = threadIdx.x; i <= a.absorb_index_n; i += kStreamBlock) {
         lds_index[used + i] = a.absorb_index[i];
       }
@@ -1068,6 +1120,15 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
     const bool uniform_window =
         windowed && t.tile_uniform &&
         __builtin_amdgcn_readfirstlane((int)t.tile_uniform[cur_tile]) != 0;
+    /* ... then every history of the chunk starts in a cell of that density (the chunk's records
+     * were sorted by the tile of their cell: they are inside the tile, hence the window): one
+     * scalar load per chunk instead of a load per history that waits for the record's */
+    double window_density = 0.0;
+    if (kCarried && uniform_window) {
+      const int tile_x = (cur_tile % t.tiles_x) << t.tile_shift;
+      const int tile_y = (cur_tile / t.tiles_x) << t.tile_shift;
+      window_density = a.density[(size_t)tile_y * (size_t)a.nx + (size_t)tile_x];
+    }
     /* may a history that leaves the window wait for another pass?  (all lanes or none: the
      * wave-uniform condition as a lane mask -- and a mask like any other to the compiler:
      * knowing it is all or nothing, it selects between the lanes' mask and zero with three
@@ -1132,6 +1193,14 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                              * workgroups do not poll for it until they give up) */
             } else {
             pid = fresh ? mine : (int)src; /* this history's slot in rec_out */
+            /* (asked for with the record, not after it: TiledArgs::micro_in) */
+            double micro = 0.0, minus_log_rn0 = 0.0;
+            if (kCarried) {
+              micro = fresh ? t.micro_in[src] : t.micro_out[src];
+              if (fresh) {
+                minus_log_rn0 = t.mlog_in[src];
+              }
+            }
             bool bad_load = false;
             if (from_queue || (queues && !fresh)) {
               /* stored by another workgroup of this launch: around the L1 (neutral_history.h);
@@ -1149,17 +1218,25 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             if (fresh) {
               /* who lives in the slot / where the particle lives: what the write-back (or a
                * decomposed store's compaction) goes by, without reading 80-B records */
-              if (kDomain) {
-                t.id_out[pid] = h.id;
-              } else if (t.slots_by_id) {
+              t.id_out[pid] = h.id; /* (coalesced: next step's first draw goes by it) */
+              if (!kDomain && t.slots_by_id) {
                 t.slot_of_id[h.id] = (unsigned)pid;
+              }
+              if (kCarried) {
+                t.micro_out[pid] = micro; /* (a streaming history keeps its energy) */
               }
             }
             if (bad_load) {
               atomicAdd(&a.counters->aborted, 1u);
               ended = true; /* (as above) */
             } else {
-            if (fresh) {
+            if (kCarried) {
+              if (fresh) {
+                prologue_carried<kChecked>(h, a, micro, minus_log_rn0, uniform_window, window_density);
+              } else {
+                resume_carried<kChecked>(h, a, micro, uniform_window, window_density);
+              }
+            } else if (fresh) {
               prologue<kSameTables, kChecked>(h, a, ix);
             } else {
               resume<kSameTables, kChecked>(h, a, ix); /* a migrant: mid-history, no draw pending */
@@ -1661,11 +1738,12 @@ hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, 
 
 /* ---- launcher ---------------------------------------------------------------------- */
 
-size_t tiled_lds_bytes(const SolveArgs& a) {
+size_t tiled_lds_bytes(const SolveArgs& a, bool carried) {
   const int cells = a.flux_tally ? 2 * kWindowCellsWithFlux * (kWindowCellsWithFlux + kWindowRowPad)
                                  : kWindow * (kWindow + kWindowRowPad);
-  return (a.same_tables ? stream_lds_payload_bytes<true>(a, cells)
-                        : stream_lds_payload_bytes<false>(a, cells)) +
+  return (carried ? stream_lds_payload_bytes<true, false>(a, cells)
+                  : a.same_tables ? stream_lds_payload_bytes<true>(a, cells)
+                                  : stream_lds_payload_bytes<false>(a, cells)) +
          kStreamLdsControlBytes;
 }
 
@@ -1725,14 +1803,31 @@ void tiled_geometry(int nx, int ny, int nparticles, int tile_shift, int* tiles_x
 }
 
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
-                                 unsigned* slot_of_id, int tiles_x, int tile_shift, int x_off, int y_off,
-                                 int n, hipStream_t stream) {
+                                 unsigned* slot_of_id, unsigned* ids, int tiles_x, int tile_shift,
+                                 int x_off, int y_off, int n, hipStream_t stream) {
   if (n > 0) {
     hipLaunchKernelGGL(import_records_kernel, dim3((n + kSortBlock - 1) / kSortBlock),
-                       dim3(kSortBlock), 0, stream, p, rec, info, slot_of_id, tiles_x, tile_shift, x_off,
-                       y_off, n);
+                       dim3(kSortBlock), 0, stream, p, rec, info, slot_of_id, ids, tiles_x, tile_shift,
+                       x_off, y_off, n);
   }
   return hipGetLastError();
+}
+
+hipError_t launch_refresh_micro(const SolveArgs& a, const TiledArgs& t, hipStream_t stream) {
+  if (t.sort_end > 0) {
+    hipLaunchKernelGGL(refresh_micro_kernel, dim3((t.sort_end + kSortBlock - 1) / kSortBlock),
+                       dim3(kSortBlock), 0, stream, a, t);
+  }
+  return hipGetLastError();
+}
+
+/* the stream kernel's instantiations that start histories from the carried values: identical
+ * tables (one microscopic cross section per energy), one rank's whole mesh (a decomposed store's
+ * records come and go between ranks without them), no tile queues (records that change hands
+ * inside a launch) */
+bool tiled_uses_carried(const SolveArgs& a, const TiledArgs& t) {
+  return kCarriedStart && a.same_tables && !a.decomposed && !t.queue_entries && t.micro_in &&
+         t.micro_out && t.mlog_in;
 }
 
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
@@ -1837,7 +1932,8 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   t.refill_min = kStreamRefillMin;
   /* (plan.stream_passes is what the step before needed, plus one) */
   t.stream_repeat = (plan.stream_passes <= 2) ? kStreamRepeatOnePass : kStreamRepeat;
-  const size_t lds = tiled_lds_bytes(a);
+  t.carried = tiled_uses_carried(a, t) ? 1 : 0;
+  const size_t lds = tiled_lds_bytes(a, t.carried != 0);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
@@ -1891,6 +1987,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.tile_shift = t.tile_shift;
   c.susp = t.susp;
   c.susp_track = t.susp_track;
+  c.micro = t.carried ? t.micro_out : nullptr;
   c.steal = t.steal;
   c.emigrants = &t.ctrl[kCtrlEmigrants];
   if (t.fine_index && c.same_tables) {
