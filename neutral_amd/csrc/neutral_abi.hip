@@ -105,7 +105,7 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   a.tiles_x = 0;
   a.tile_shift = 4;
   a.susp = nullptr;
-  a.micro = nullptr;
+  a.carried = nullptr;
   a.steal = nullptr;
   a.occupancy_rows = 0;
   /* the launches' tuning: read from the environment and the runtime once per store -- here for
@@ -529,9 +529,9 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     unsigned* swap_id = t.id_in;
     t.id_in = t.id_out;
     t.id_out = swap_id;
-    double* swap_micro = t.micro_in;
-    t.micro_in = t.micro_out;
-    t.micro_out = swap_micro;
+    neutral::CarriedStart* swap_carried = t.carried_in;
+    t.carried_in = t.carried_out;
+    t.carried_out = swap_carried;
     if (!t.carried) {
       g.carried_valid = false; /* (a step that looked up and drew itself kept none of it) */
     }

@@ -137,7 +137,7 @@ struct State {
   neutral::ParticleView rec_owner_view = {}; /* its arrays, for the write-back */
   int rec_count = 0;
   bool rec_valid = false;          /* records hold the current state */
-  bool carried_valid = false;      /* ... and TiledArgs::micro_in the cross section of every live
+  bool carried_valid = false;      /* ... and TiledArgs::carried_in the cross section of every live
                                       record's energy in the tables of the cached view */
   bool soa_valid = true;           /* SoA arrays hold the current state */
   int lazy_export = 0;

@@ -145,7 +145,7 @@ void sync_soa() {
  * layout changes): the next tiled step imports it again. */
 void drop_records() {
   g.rec_valid = false;
-  g.carried_valid = false; /* (TiledArgs::micro_in belongs to the records) */
+  g.carried_valid = false; /* (TiledArgs::carried_in belongs to the records) */
   g.suspended_share = -1.0;
   g.free_count = 0; /* (slots emigrants left are holes of the records, not of the arrays) */
   g.plan_passes = 0;
@@ -176,7 +176,7 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
   if (grow) {
     void* old[] = {t.order,  t.collide_queue, t.tile_count, t.tile_offset, t.tile_cursor, t.rec_in,
                    t.rec_out, t.info_in,      t.info_out,   t.susp,        t.id_in,       t.id_out,
-                   t.slot_of_id, t.tile_uniform, t.micro_in, t.micro_out, t.mlog_in};
+                   t.slot_of_id, t.tile_uniform, t.carried_in, t.carried_out};
     for (void* p : old) {
       if (p) HIP_CHECK(hipFree(p));
     }
@@ -194,9 +194,8 @@ void ensure_tiled_workspace(int nx, int ny, int nparticles_now, int capacity) {
     HIP_CHECK(hipMalloc((void**)&t.id_in, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.id_out, sizeof(unsigned) * n));
     HIP_CHECK(hipMalloc((void**)&t.slot_of_id, sizeof(unsigned) * n));
-    HIP_CHECK(hipMalloc((void**)&t.micro_in, sizeof(double) * n));
-    HIP_CHECK(hipMalloc((void**)&t.micro_out, sizeof(double) * n));
-    HIP_CHECK(hipMalloc((void**)&t.mlog_in, sizeof(double) * n));
+    HIP_CHECK(hipMalloc((void**)&t.carried_in, sizeof(neutral::CarriedStart) * n));
+    HIP_CHECK(hipMalloc((void**)&t.carried_out, sizeof(neutral::CarriedStart) * n));
     HIP_CHECK(hipMalloc((void**)&t.susp, sizeof(neutral::SuspendExtra) * n));
     HIP_CHECK(hipMalloc((void**)&t.tile_count, sizeof(unsigned) * nb));
     HIP_CHECK(hipMalloc((void**)&t.tile_offset, sizeof(unsigned) * nb));

@@ -732,9 +732,9 @@ __device__ __forceinline__ void resume(History& h, const SolveArgs& a,
  * section -- a function of the energy, which a history keeps from the end of one timestep to
  * the start of the next and through every facet of its flight -- and the first sample of the
  * step, -log(rn0), a function of the particle id and the timestep alone.  The first travels with
- * the record (TiledArgs::micro_in / micro_out: written by whoever last changed the energy), the
+ * the record (TiledArgs::carried_in / carried_out: written by whoever last changed the energy), the
  * second is worked out by the counting sort's placement pass, which touches every live record
- * once per step and waits on atomics while it does (TiledArgs::mlog_in).  What is left of a
+ * once per step and waits on atomics while it does (CarriedStart::minus_log_rn0).  What is left of a
  * start is a chain of three dependent loads (sorted order -> record -> density) instead of
  * seven (+ index, 1-3 table probes, the bracket's keys and values), and a third of the vector
  * instructions: the refill was a quarter of the stream stage's wave time

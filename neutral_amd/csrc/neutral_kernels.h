@@ -53,6 +53,12 @@ struct alignas(16) SuspendExtra {
 /* (with the scalar-flux tally the pending weight * path length of such a history
  * lives in a parallel array of doubles: TiledArgs::susp_track) */
 
+/* what the start of a history does not depend on (TiledArgs::carried_in) */
+struct alignas(16) CarriedStart {
+  double micro;          /* microscopic cross section of the record's energy (identical tables) */
+  double minus_log_rn0;  /* -log of the timestep's first sample (omp3/neutral.c:127-131) */
+};
+
 struct InjectArgs {
   int nparticles;
   uint64_t pid_base;
@@ -166,8 +172,8 @@ struct SolveArgs {
   int tile_shift;            /* log2 of the tile edge in cells (4..7) */
   SuspendExtra* susp;        /* per-record side store of time-sliced histories (queue mode) */
   double* susp_track;        /* ... their pending weight * path length (scalar flux only) */
-  double* micro;             /* per-record microscopic cross section the collision stage leaves for
-                                the next timestep's start (TiledArgs::micro_out; null: not kept) */
+  CarriedStart* carried;     /* per-record microscopic cross section the collision stage leaves for
+                                the next timestep's start (TiledArgs::carried_out; null: not kept) */
   int steal_min;              /* collision stage: waiting histories a ring must hold to be taken
                                  from by a CU-mate (0: no stealing; NEUTRAL_STEAL_MIN) */
   StealWork* steal;           /* [device] rings' control words and CU lists (null: no stealing) */
@@ -212,20 +218,18 @@ struct TiledArgs {
   unsigned* slot_of_id;    /* nparticles: where particle id's record is -- what the write-back
                               goes by */
   /* What a history's start does not depend on, kept per record slot so that the stream kernel
-   * starts from it (neutral_history.h: prologue_carried; identical tables, one rank's whole
-   * mesh, no tile queues -- the other instantiations look up and draw as before):
-   *   micro_in / micro_out  the microscopic cross section of the record's energy, next to
-   *                         rec_in / rec_out: written by whoever places the record (pass 0 of
-   *                         the stream kernel copies it across) or changes its energy (the
-   *                         collision stage, where it ends a history); valid for every live
-   *                         slot of rec_in whenever carried_valid says so -- the host runs
-   *                         refresh_micro_kernel first when it does not (a store just imported,
-   *                         a table view just rebuilt);
-   *   mlog_in               -log(rn0) of this timestep's first draw, per slot of rec_in: the
-   *                         counting sort's placement pass (pass 0) works it out from id_in. */
-  double* micro_in;
-  double* micro_out;
-  double* mlog_in;
+   * starts from it (CarriedStart above; neutral_history.h: prologue_carried; identical tables, one
+   * rank's whole mesh, no tile queues -- the other instantiations look up and draw as before):
+   * carried_in / carried_out next to rec_in / rec_out.  `micro` is written by whoever places the
+   * record (pass 0 of the stream kernel copies it across) or changes its energy (the collision
+   * stage, where it ends a history), and is valid for every live slot of rec_in whenever the host
+   * says so (it runs refresh_micro_kernel first when not: a store just imported, a table view
+   * just rebuilt); `minus_log_rn0` of carried_in is worked out by the counting sort's placement
+   * pass (pass 0) from id_in.  One 16-byte pair per slot: the stream kernel's gather is one
+   * 64-byte sector per history beside the record's two, not two (the split deck, whose stream
+   * kernel is nothing but refills, ran 6 % slower with two arrays: profiles/r05/experiments). */
+  CarriedStart* carried_in;
+  CarriedStart* carried_out;
   int carried;             /* 1: this step's stream kernel starts from them (set per step) */
   /* The graveyard.  Records [sort_end, nparticles) belong to particles that were dead when
    * the LAST step began: they keep their slots for good, in both record buffers, and take
@@ -365,7 +369,7 @@ size_t tiled_lds_bytes(const SolveArgs& a, bool carried = false);
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
                                  unsigned* slot_of_id, unsigned* ids, int tiles_x, int tile_shift,
                                  int x_off, int y_off, int n, hipStream_t stream);
-/* micro_in[slot] for every live record of t.rec_in, by plain bisection of the scatter table (no
+/* carried_in[slot].micro for every live record of t.rec_in, by plain bisection of the scatter table (no
  * index: independent of the cached view) -- after an import, after the table view was rebuilt */
 hipError_t launch_refresh_micro(const SolveArgs& a, const TiledArgs& t, hipStream_t stream);
 /* does this step's stream kernel start histories from the carried values? */

@@ -388,10 +388,10 @@ __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, i
     store_record(h, a, a.rec[pid], state);
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
-    if (kCarriesMicro && a.micro) {
+    if (kCarriesMicro && a.carried) {
       /* what the next timestep's start takes from the record's slot instead of looking it up
-       * (TiledArgs::micro_out): the cross section of the energy the history ends with */
-      a.micro[pid] = h.micro_s;
+       * (TiledArgs::carried_out): the cross section of the energy the history ends with */
+      a.carried[pid].micro = h.micro_s;
     }
     if (a.export_view) {
       /* the interface's arrays get the final state here (the write-back of the histories that

@@ -285,11 +285,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TiledArgs t) {
  * reservation with LDS atomics.  (The order inside a tile is whatever the atomics
  * make it: nothing depends on it -- histories are independent and the tally is a
  * sum.) */
-/* Pass 0 also makes every live history's first draw of the timestep (TiledArgs::mlog_in):
+/* Pass 0 also makes every live history's first draw of the timestep (TiledArgs::carried_in):
  * Threefry and the logarithm, 250 vector instructions per record, in a kernel that otherwise
  * waits on atomics -- instead of at the head of the stream kernel's refill chain. */
 __device__ __forceinline__ void draw_for_slot(const SolveArgs& a, const TiledArgs& t, long long slot) {
-  t.mlog_in[slot] = draw_first_flight(a.pid_base + (uint64_t)t.id_in[slot], a.master_key);
+  t.carried_in[slot].minus_log_rn0 = draw_first_flight(a.pid_base + (uint64_t)t.id_in[slot], a.master_key);
 }
 
 __global__ __launch_bounds__(kSortBlock) void tile_scatter_kernel(SolveArgs a, TiledArgs t) {
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kSortBlock) void import_records_kernel(ParticleView
   }
 }
 
-/* micro_in[slot] for every live record of rec_in (TiledArgs::micro_in): what the stream kernel's
+/* carried_in[slot].micro for every live record of rec_in (TiledArgs::carried_in): what the stream kernel's
  * carried start takes for granted, made good after an import or a rebuilt table view.  Plain
  * bisection -- the same unique bracket as the indexed search, hence the same value -- so that
  * nothing here depends on the cached indexes. */
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kSortBlock) void refresh_micro_kernel(SolveArgs a, 
   }
   const double energy = t.rec_in[i].energy;
   const int ind = cs_bracket(a.scatter_keys, a.scatter_n, energy);
-  t.micro_in[i] = a.checked ? cs_interpolate<true>(a.scatter_keys, a.scatter_values, ind, energy)
+  t.carried_in[i].micro = a.checked ? cs_interpolate<true>(a.scatter_keys, a.scatter_values, ind, energy)
                             : cs_interpolate<false>(a.scatter_keys, a.scatter_values, ind, energy);
 }
 
@@ -1193,13 +1193,12 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                              * workgroups do not poll for it until they give up) */
             } else {
             pid = fresh ? mine : (int)src; /* this history's slot in rec_out */
-            /* (asked for with the record, not after it: TiledArgs::micro_in) */
+            /* (asked for with the record, not after it: TiledArgs::carried_in) */
             double micro = 0.0, minus_log_rn0 = 0.0;
             if (kCarried) {
-              micro = fresh ? t.micro_in[src] : t.micro_out[src];
-              if (fresh) {
-                minus_log_rn0 = t.mlog_in[src];
-              }
+              const CarriedStart cs = fresh ? t.carried_in[src] : t.carried_out[src]; /* (one 16-byte load) */
+              micro = cs.micro;
+              minus_log_rn0 = cs.minus_log_rn0; /* (a migrant's: not looked at) */
             }
             bool bad_load = false;
             if (from_queue || (queues && !fresh)) {
@@ -1223,7 +1222,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
                 t.slot_of_id[h.id] = (unsigned)pid;
               }
               if (kCarried) {
-                t.micro_out[pid] = micro; /* (a streaming history keeps its energy) */
+                t.carried_out[pid].micro = micro; /* (a streaming history keeps its energy) */
               }
             }
             if (bad_load) {
@@ -1826,8 +1825,8 @@ hipError_t launch_refresh_micro(const SolveArgs& a, const TiledArgs& t, hipStrea
  * records come and go between ranks without them), no tile queues (records that change hands
  * inside a launch) */
 bool tiled_uses_carried(const SolveArgs& a, const TiledArgs& t) {
-  return kCarriedStart && a.same_tables && !a.decomposed && !t.queue_entries && t.micro_in &&
-         t.micro_out && t.mlog_in;
+  return kCarriedStart && a.same_tables && !a.decomposed && !t.queue_entries && t.carried_in &&
+         t.carried_out;
 }
 
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
@@ -1987,7 +1986,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   c.tile_shift = t.tile_shift;
   c.susp = t.susp;
   c.susp_track = t.susp_track;
-  c.micro = t.carried ? t.micro_out : nullptr;
+  c.carried = t.carried ? t.carried_out : nullptr;
   c.steal = t.steal;
   c.emigrants = &t.ctrl[kCtrlEmigrants];
   if (t.fine_index && c.same_tables) {
