@@ -337,6 +337,7 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
 
     keys, values = cs_table.load()
     cores = ob.lib().orc_num_threads()
+    quota = cpu_quota_cores()
 
     def run(n):
         path = decks.write_deck(deck, os.path.join(tmp, f"cpu_{n}.params"), nx=nx, ny=nx,
@@ -354,14 +355,21 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
         return steps, time.perf_counter() - t0, r
 
     # The static partition and the tally atomics of the omp3 scheme do not always
-    # scale to every hardware thread: probe a few thread counts on a small sample
-    # and time the real sample with the fastest, so the baseline is the CPU at
-    # its best.
+    # scale to every hardware thread, and a job's CPU quota may be far below the threads
+    # it can see: probe thread counts from all of them down to the quota (and below) on a
+    # small sample and time the real sample with the fastest, so the baseline is the CPU at
+    # its best.  Threads are pinned (OMP_PROC_BIND / OMP_PLACES, set in main() before any
+    # OpenMP runtime loads) and the line says so.
     n0 = 200_000
     best = None
-    for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+    candidates = {cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}
+    if quota:
+        candidates |= {max(1, int(quota)), max(1, 2 * int(quota))}
+    probed = []
+    for threads in sorted((c for c in candidates if c <= cores), reverse=True):
         ob.lib().orc_set_num_threads(threads)
         s_, t_, _ = run(n0)
+        probed.append({"threads": threads, "particle_steps_per_s": s_ / t_})
         if best is None or s_ / t_ > best[0]:
             best = (s_ / t_, threads, t_)
     cores = best[1]
@@ -372,14 +380,45 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
     steps, secs, oracle_run = run(n)
     out = {"value": steps / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
            "sample": f"{deck} {nx}x{nx}, {n} particles, {its} timesteps, "
-                     f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)"}
+                     f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)",
+           "proc_bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES"),
+           "threads_visible": len(os.sched_getaffinity(0)),
+           "cpu_quota_cores": quota,
+           "probed": probed,
+           "cpu_model": cpu_model()}
     return out, oracle_run, n
+
+
+def cpu_quota_cores():
+    """CPU time this job may use, in cores (a container's cpu.max), or None when unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def main():
     # ROCr reads this at start-up: multi-process GPU work on this pool needs dmabuf IPC
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        # the CPU baseline's threads stay where they are put (read by the OpenMP runtime when it
+        # loads, i.e. before torch or the oracle pull one in)
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
     global FLUX
     FLUX = bool(args.flux)
     domain = None
@@ -472,17 +511,26 @@ def main():
             global event totals, write-back ms)."""
             iface.set_lazy_export(lazy)
             sim.inject()
+            torch.cuda.synchronize()
             for tt in range(1, W + 1):
+                t_w = time.perf_counter()
                 sim.step(tt)
+                step_wall_ms.setdefault("warmup", []).append(1e3 * (time.perf_counter() - t_w))
             sim.inject()
             sim.tally.zero_()
             if sim.flux is not None:
                 sim.flux.zero_()
             fence()
             t0 = time.perf_counter()
-            results = [sim.step(tt) for tt in range(1, K + 1)]
+            results = []
+            walls = []
+            for tt in range(1, K + 1):
+                t_s = time.perf_counter()
+                results.append(sim.step(tt))   # (synchronous on return: main.c stops its timer there)
+                walls.append(1e3 * (time.perf_counter() - t_s))
             fence()
             elapsed = time.perf_counter() - t0
+            step_wall_ms.setdefault("lazy" if lazy else "timed", walls)
             t_wb = time.perf_counter()
             lib.neutral_hip_sync_particles(sim.particles)   # lazy: the deferred write-back
             torch.cuda.synchronize()
@@ -496,6 +544,10 @@ def main():
                    "histories": sum(r.nprocessed for r in results)}
             return results, elapsed, tot, writeback_ms
 
+        # host wall time of every solve_transport_2d call of this rank, by region (the first call of
+        # the process carries what is set up lazily: RCCL's channels at the first exchange, the
+        # table view, the workspace)
+        step_wall_ms = {}
         # ---- the headline: the library as an unmodified main.c drives it ----
         results, elapsed, tot, _ = timed_region(lazy=False)
         stats = iface.last_step()
@@ -503,13 +555,18 @@ def main():
         ranks_view = None
         if world > 1:
             import ctypes as C
+            first_call = (step_wall_ms.get("warmup") or step_wall_ms["timed"])[0]
+            timed_walls = step_wall_ms["timed"]
+            steady = timed_walls[1:] or timed_walls
             mine = [float(transport),
                     sum(r.stats.kernel_ms + r.stats.export_ms for r in results) / K,
                     sum(r.stats.stream_ms for r in results) / K,
                     sum(r.stats.collide_ms for r in results) / K,
                     sum(r.stats.exchange_ms for r in results) / K,
                     float(results[-1].stats.local_nprocessed),
-                    float(sim.n)]
+                    float(sim.n),
+                    first_call, timed_walls[0], sum(steady) / len(steady),
+                    max(r.stats.exchange_ms for r in results)]
             t = torch.zeros(world * len(mine), dtype=torch.float64, device=sim.device)
             t[rank * len(mine):(rank + 1) * len(mine)] = torch.tensor(mine, dtype=torch.float64)
             torch.cuda.synchronize()
@@ -532,7 +589,27 @@ def main():
                 "exchange_ms_per_step": spread(4),  # on the library's own stream
                 "particles_alive_last_step": spread(5),
                 "particles_in_shard": spread(6),
+                # host wall time of solve_transport_2d, per rank: the process's FIRST call (RCCL
+                # sets its channels up lazily at the first exchange; table view, workspace), the
+                # first timed step, and the mean of the timed steps after it
+                "first_call_wall_ms": spread(7),
+                "first_timed_step_wall_ms": spread(8),
+                "steady_step_wall_ms": spread(9),
             }
+            # the exchange is 1.28 MB + 160 B per step: beyond half a millisecond on any rank it
+            # is not latency-bound any more (a fallback transport, a slow link, a rank that
+            # arrives late), and the line says so instead of letting the scaling figure carry it
+            worst = max(row[10] for row in rows)
+            bar = 0.5
+            ranks_view["exchange_check"] = {
+                "worst_step_ms_any_rank": worst, "mean_ms_per_step_max_over_ranks": spread(4)["max"],
+                "bar_ms": bar, "ok": bool(spread(4)["max"] < bar),
+                "note": "exchange_ms is HIP-event time on the library's own stream: pack, two "
+                        "all-reduces (tally, step words), the add into the caller's mesh"}
+            if not ranks_view["exchange_check"]["ok"] and rank == 0:
+                print(f"bench.py: the tally exchange takes {spread(4)['max']:.3f} ms per step on the "
+                      f"slowest rank (bar {bar} ms; worst single step {worst:.3f} ms): the N > 1 figure "
+                      f"is bound by it, see ranks.exchange_ms_per_step", file=sys.stderr, flush=True)
             if domain is not None:
                 mine2 = [sum(r.stats.exchange_rounds for r in results) / K,
                          sum(r.stats.emigrants for r in results) / K,

@@ -159,8 +159,8 @@ void comms_start_from_env(void) {
       const int fd = accept(ls, NULL, NULL);
       if (fd < 0) {
         if (now_s() > deadline) {
-          TERMINATE("rank 0: only %d of %d ranks arrived at %s:%d.\n", joined, g_nranks, addr,
-                    port);
+          TERMINATE("rank 0: only %d of %d ranks arrived at %s:%d (%d other connections were "
+                    "turned away).\n", joined, g_nranks, addr, port, rejected);
         }
         continue;
       }
@@ -168,7 +168,9 @@ void comms_start_from_env(void) {
       /* the handshake keeps a receive timeout: a stray or half-open connection to the
        * port (or one that does not know the launcher's word, or names a rank that is
        * taken) is dropped and the wait for the real ranks goes on */
-      struct timeval hs = {5, 0};
+      /* (one second: a rank of this launch sends its hello right behind its connect; a stray
+       * that says nothing holds the others up for no longer than that) */
+      struct timeval hs = {1, 0};
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hs, sizeof(hs));
       unsigned long long hello[2] = {0, 0};
       /* (the rank is compared as the 64-bit word it arrives as: 0x1_0000_0001 is not rank 1) */
@@ -183,11 +185,15 @@ void comms_start_from_env(void) {
       }
       if (!known) {
         close(fd);
-        /* strays cost up to the handshake timeout each: a port somebody keeps knocking on
-         * is a reason to stop, not to wait out the launch's whole time limit */
-        if (++rejected > 64) {
-          TERMINATE("rank 0: %d connections to %s:%d that are not ranks of this launch; set "
-                    "NEUTRAL_COMM_PORT to a port of its own.\n", rejected, addr, port);
+        /* A stray is turned away and the wait for the ranks goes on: what bounds it is the
+         * launch's own time limit, not a count -- a port scanner or a stale client must not be
+         * able to end a running launch by knocking often enough (round-4 advisor finding).  The
+         * limit is looked at here too: accept() never times out while somebody keeps knocking. */
+        rejected++;
+        if (now_s() > deadline) {
+          TERMINATE("rank 0: only %d of %d ranks arrived at %s:%d within the time limit (%d other "
+                    "connections were turned away: set NEUTRAL_COMM_PORT to a port of its own).\n",
+                    joined, g_nranks, addr, port, rejected);
         }
         continue;
       }
@@ -216,11 +222,20 @@ void comms_start_from_env(void) {
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
     const unsigned long long hello[2] = {handshake_nonce(), (unsigned long long)g_rank};
     send_all(fd, hello, sizeof(hello));
-    /* in or out, said at once (bounded wait: rank 0 answers a hello within its handshake) */
-    struct timeval hs = {30, 0};
+    /* in or out: rank 0 answers a hello as soon as it gets to it -- it takes the connections in
+     * turn, strays included, so the wait for the verdict lasts as long as rank 0's own wait for
+     * its ranks does (the launch's time limit), not a fixed half minute; and no answer is told
+     * apart from a refusal */
+    double left = deadline - now_s();
+    left = (left < 5.0) ? 5.0 : left;
+    struct timeval hs = {(time_t)left, 0};
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hs, sizeof(hs));
     unsigned long long verdict = 0;
-    if (!recv_or_give_up(fd, &verdict, sizeof(verdict)) || verdict != 1ull) {
+    if (!recv_or_give_up(fd, &verdict, sizeof(verdict))) {
+      TERMINATE("rank %d: rank 0 at %s:%d took the connection but gave no verdict within the time "
+                "limit (it is busy with other connections, or gone).\n", g_rank, addr, port);
+    }
+    if (verdict != 1ull) {
       TERMINATE("rank %d was turned down by rank 0 at %s:%d (another process holds this rank, or "
                 "NEUTRAL_COMM_NONCE differs between the ranks).\n", g_rank, addr, port);
     }

@@ -48,8 +48,17 @@ def test_two_rank_bench_equals_one_rank(tmp_path):
     assert rk["transport_asked"] == "host" and rk["transport_per_rank"] == ["host", "host"]
     assert isinstance(rk["rccl_version"], int) and rk["rccl_version"] >= 0
     for key in ("device_ms_per_step", "stream_ms_per_step", "collide_ms_per_step",
-                "exchange_ms_per_step", "particles_alive_last_step", "particles_in_shard"):
+                "exchange_ms_per_step", "particles_alive_last_step", "particles_in_shard",
+                "first_call_wall_ms", "first_timed_step_wall_ms", "steady_step_wall_ms"):
         assert len(rk[key]["per_rank"]) == 2 and rk[key]["min"] <= rk[key]["max"], key
+    # the first call of the process (lazy set-up) is told apart from the steady state
+    assert rk["first_call_wall_ms"]["min"] > 0 and rk["steady_step_wall_ms"]["min"] > 0
+    assert rk["first_call_wall_ms"]["max"] >= rk["steady_step_wall_ms"]["min"]
+    # the exchange is judged against its bar in the line itself (the host route of this test
+    # is allowed to miss it: what is asserted is that the line says which)
+    chk = rk["exchange_check"]
+    assert chk["bar_ms"] == 0.5 and chk["worst_step_ms_any_rank"] >= chk["mean_ms_per_step_max_over_ranks"] > 0
+    assert chk["ok"] == (chk["mean_ms_per_step_max_over_ranks"] < chk["bar_ms"])
     assert rk["device_ms_per_step"]["min"] > 0 and rk["exchange_ms_per_step"]["min"] > 0
     assert sum(rk["particles_in_shard"]["per_rank"]) == 3000001
     assert 0 < sum(rk["particles_alive_last_step"]["per_rank"]) <= 3000001

@@ -65,3 +65,54 @@ def test_a_missing_rank_is_an_error_not_a_hang(selftest):
     out = subprocess.run([selftest], env=env, capture_output=True, text=True, timeout=60)
     assert out.returncode != 0
     assert "only 1 of 2 ranks arrived" in out.stderr
+
+
+def test_strays_do_not_end_a_launch(selftest):
+    """A hundred connections that are not ranks of the launch (garbage hellos, and silent ones
+    that wait out the handshake timeout) knock on rank 0's port while it waits for rank 1: each is
+    turned away, none of them ends the launch (an absolute count of 64 used to: round-4 advisor
+    finding), and rank 1, arriving last behind them, is still let in and told so."""
+    import threading
+    import time
+    port = free_port()
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               NEUTRAL_COMM_TIMEOUT="60")
+    rank0 = subprocess.Popen([selftest], env=dict(env, RANK="0", LOCAL_RANK="0"),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    comm_port = port + 1          # (comms_ranks.c: NEUTRAL_COMM_PORT defaults to MASTER_PORT + 1)
+
+    def knock(payload):
+        for _ in range(200):
+            try:
+                s = socket.create_connection(("127.0.0.1", comm_port), timeout=2)
+                break
+            except OSError:
+                time.sleep(0.05)
+        else:
+            return
+        try:
+            if payload:
+                s.sendall(payload)
+                s.settimeout(5)
+                try:
+                    s.recv(8)
+                except OSError:
+                    pass
+            else:
+                time.sleep(1.5)   # says nothing: rank 0's handshake timeout turns it away
+        finally:
+            s.close()
+
+    strays = [threading.Thread(target=knock, args=(os.urandom(16),)) for _ in range(97)]
+    strays += [threading.Thread(target=knock, args=(b"",)) for _ in range(3)]
+    for t in strays:
+        t.start()
+    for t in strays:
+        t.join()
+    rank1 = subprocess.Popen([selftest], env=dict(env, RANK="1", LOCAL_RANK="1"),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out1, err1 = rank1.communicate(timeout=120)
+    out0, err0 = rank0.communicate(timeout=120)
+    assert rank0.returncode == 0, (out0, err0)
+    assert rank1.returncode == 0, (out1, err1)
+    assert out0.strip() == "rank 0 of 2 ok" and out1.strip() == "rank 1 of 2 ok"

@@ -134,6 +134,37 @@ def test_two_gpus_exchange_over_rccl(tmp_path, cs):
 
 
 @pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
+@pytest.mark.skipif(_visible_gpus() < 2, reason="ncclSend/ncclRecv between GPUs needs two of them (the test box has one)")
+def test_two_gpus_exchange_particles_over_rccl(tmp_path, cs):
+    """`neutral.hip --gpus 2 --decompose 2x1` on two DIFFERENT GPUs: the emigrants of every round
+    travel by ncclSend / ncclRecv in one group (neutral_comm.hip: comm_exchange_bytes), not over the
+    host links -- so that this branch first runs under a comparison with the CPU oracle and with
+    the one-rank run, not under the bench.  Per-step event counts exact, tally 1e-10 / 1e-12.
+    (Turns itself on wherever two GPUs are visible; the pool's test box has one.)"""
+    from neutral_amd import cs_table, decks
+    run = tmp_path / "arch" / "neutral"
+    (run / "problems").mkdir(parents=True)
+    (tmp_path / "arch" / "arch.params").write_text("width 1.0\nheight 1.0\nsim_end 100.0\n")
+    cs_table.write_files(str(run))
+    rel = os.path.join("problems", "csp.params")
+    decks.write_deck("csp", str(run / rel))
+    sets = []
+    for kv in ("nx=128", "ny=128", "nparticles=200001", "iterations=4", "dt=1.0e-6"):
+        sets += ["--set", kv]
+    one, _ = _run_driver(str(run), rel, sets)
+    many, err = _run_driver(str(run), rel, sets + ["--gpus", "2", "--decompose", "2x1"],
+                            {"NEUTRAL_COMM_TIMEOUT": "120"})
+    f1, c1, p1, t1 = _numbers(one)
+    fn, cn, pn, tn = _numbers(many)
+    fo, co, po, to = _oracle_numbers(tmp_path, cs, **CSP_128)
+    assert (fo, co, po) == (fn, cn, pn), many[-1500:]      # the oracle first
+    assert abs(tn - to) <= 1e-10 * abs(to)
+    assert (f1, c1, p1) == (fn, cn, pn), (one[-1500:], many[-1500:])
+    assert abs(tn - t1) <= 1e-12 * abs(t1)
+    assert "over RCCL" in err, err[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(OWN_DRIVER), reason="neutral.hip not built")
 @pytest.mark.parametrize("nranks,grid", [(2, "2x1"), (4, "2x2")])
 def test_forked_ranks_with_a_decomposed_mesh(tmp_path, cs, nranks, grid):
     """`neutral.hip --gpus N --decompose PXxPY`: every rank holds a block of the mesh and
