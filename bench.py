@@ -131,6 +131,9 @@ PRIMARY_EVENT = {"stream_kernel": "facets", "history_regroup_kernel": "collision
 FLUX = False  # --flux: the committed PMC coefficients are those of the kernels without it
 
 
+SHARE_OF = None  # N > 1 (or --nparticles = workload / N): prefer the coefficients of that share
+
+
 def profile_entry(deck, nx, variant, kernel):
     """The committed rocprofv3 PMC figures of `kernel` for this deck and mesh
     (profiles/pmc_per_event.json, made by tools/pmc_events.py from separate --pmc
@@ -142,11 +145,15 @@ def profile_entry(deck, nx, variant, kernel):
             table = json.load(f)
     except OSError:
         return None
+    found = None
     for e in table.get("entries", []):
         if (e["deck"], e["nx"], e["variant"], e["kernel"], bool(e.get("flux", False))) == \
                 (deck, nx, variant, kernel, FLUX):
-            return e
-    return None
+            if e.get("share_of") == SHARE_OF:
+                return e
+            if e.get("share_of") is None:
+                found = e   # (no coefficients of that share: the whole workload's)
+    return found
 
 
 HOT_LOOP = {"stream_kernel": "facet", "history_regroup_kernel": "collide",
@@ -175,7 +182,14 @@ def isa_mix(kernel):
     return mix
 
 
-def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None):
+# full-load and idle readings of the hardware-only figure below, on kernels whose load is known by
+# construction (tools/micro/pmc_calibration.hip, profiles/r05/pmc_calibration.log)
+HW_VALU_BUSY_CALIBRATION = {"independent v_fma_f64, 4 waves/SIMD": 0.938, "1 wave/SIMD": 0.743,
+                            "fma blocks separated by s_sleep": 0.400}
+NOMINAL_GHZ = 2.4
+
+
+def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None, clock_ghz=None):
     """Vector-issue roofline of one kernel: issue cycles of THIS run's launches (wave-level
     vector instructions per event from the committed PMC passes x this run's events x the
     mean cost of an instruction of the kernel's hot loop, priced opcode by opcode) over
@@ -212,10 +226,44 @@ def issue_roofline(deck, nx, variant, kernel, ev, launches, collide_passes=None)
                       "(tools/micro/valu_opcodes.hip, v_mul_f64 = 4); clock 2.4 GHz nominal",
            "profiled": e.get("source", "profiles/pmc_per_event.json")}
     if collide_passes and HOT_LOOP.get(kernel) == "collide":
-        # the same figure from the kernel's own dynamic count: wave-level collision passes
-        # x the static issue cycles of one trip of the pass loop (rare paths included)
-        out["frac_from_pass_count"] = collide_passes * mix["issue_cycles_per_trip"] / avail
+        # the same figure from the kernel's own dynamic count of wave-level collision passes x what a
+        # pass issues: MEASURED per pass in the profiled run (refills and hand-backs included), and
+        # -- an upper bound, kept for continuity -- the static trip of the pass loop, which also
+        # counts the instructions of the blocks a trip rarely enters
         out["collision_passes_per_launch"] = collide_passes / launches
+        out["frac_from_pass_count_static_trip"] = collide_passes * mix["issue_cycles_per_trip"] / avail
+        out["static_trip_valu_insts"] = mix.get("valu_instructions")
+        per_pass = e.get("valu_insts_per_collision_pass")
+        if per_pass:
+            out["valu_insts_per_pass_measured"] = per_pass
+            out["frac_from_pass_count"] = collide_passes * per_pass * mean / avail
+        else:
+            out["frac_from_pass_count"] = out["frac_from_pass_count_static_trip"]
+    # bracket: the pricing's own (opcodes priced by family), widened to hold the pass-count route
+    routes = [out["frac"]] + ([out["frac_from_pass_count"]] if "frac_from_pass_count" in out else [])
+    out["frac_bracket"] = {"low": min([out["frac_low"]] + routes), "high": max([out["frac_high"]] + routes),
+                           "half_width_rel": (max([out["frac_high"]] + routes) - min([out["frac_low"]] + routes)) /
+                           (2.0 * out["frac"])}
+    # the clock there WAS: measured in the kernel's own launches of this run (one wave per launch,
+    # shader-clock ticks per 100-MHz tick); `frac` divides by the nominal 2.4 GHz
+    if clock_ghz:
+        out["shader_clock_ghz_measured"] = clock_ghz
+        out["frac_at_measured_clock"] = out["frac"] * NOMINAL_GHZ / clock_ghz
+    # hardware only, from the profiled run's SQ counters (no pricing, no clock): quads of vector-ALU
+    # activity over the SQ-busy cycles of the launches x 1024 SIMDs.  SQ_ACTIVE_INST_VALU counts one
+    # 4-cycle quad per v_fma_f64 (calibration) and rounds cheaper 32-bit opcodes UP to a quad, so
+    # this reads high on integer-heavy code; the calibration readings say what full and idle look like
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_BUSY_CYCLES"):
+        out["hw"] = {
+            "valu_active_share_of_sq_busy_cycles": 4.0 * c["SQ_ACTIVE_INST_VALU"] /
+            (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0),
+            "calibration": HW_VALU_BUSY_CALIBRATION,
+            "cycles_per_valu_inst_upper": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
+            "source": "SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES (32 SQ instances), SQ_INSTS_VALU of " +
+                      str(e.get("source", "profiles/pmc_per_event.json"))}
+        if e.get("kernel_ms_per_launch_same_flags") and e.get("dispatches_profiled"):
+            busy = c["SQ_BUSY_CYCLES"] * e["events_profiled"] / 32.0 / e["dispatches_profiled"]
+            out["hw"]["shader_clock_ghz_under_profiler"] = busy / (e["kernel_ms_per_launch_same_flags"] * 1e6)
     if c.get("SQ_ACTIVE_INST_VALU"):
         out["lane_utilisation"] = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / \
             (c["SQ_ACTIVE_INST_VALU"] * 64.0)
@@ -382,7 +430,7 @@ def cpu_baseline(deck, nx, its, target_seconds, tmp):
            "sample": f"{deck} {nx}x{nx}, {n} particles, {its} timesteps, "
                      f"{steps} particle-steps in {secs:.2f} s (CPU oracle, OpenMP static)",
            "proc_bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES"),
-           "threads_visible": len(os.sched_getaffinity(0)),
+           "threads_visible": os.cpu_count(),
            "cpu_quota_cores": quota,
            "probed": probed,
            "cpu_model": cpu_model()}
@@ -663,6 +711,18 @@ def main():
             same = bool(stats.same_tables)
             variant = int(stats.variant)
             kernels = []
+
+            def clock_of(name, res):
+                """mean shader clock the kernel's launches of `res` ran at (this rank's, measured
+                in the kernels), or None when the variant does not measure it"""
+                field = {"stream_kernel": "stream_clock_ghz",
+                         "history_regroup_kernel": "collide_clock_ghz"}.get(name)
+                v = [getattr(r.stats, field) for r in res if field and getattr(r.stats, field) > 0]
+                return (sum(v) / len(v)) if v else None
+            global SHARE_OF
+            full = WORKLOADS[args.workload][2]
+            SHARE_OF = world if world > 1 else (round(full / ntotal) if ntotal < full and
+                                                abs(full / ntotal - round(full / ntotal)) < 1e-9 else None)
             for name, ev in kev.items():
                 kernels.append({"name": name, "ms_per_launch": ev["ms"] / K,
                                 "events_per_launch": {k: ev[k] / K for k in
@@ -670,7 +730,8 @@ def main():
                                                        "census")},
                                 "valu_issue": issue_roofline(
                                     deck, nx, variant, name, ev, K,
-                                    sum(r.stats.collide_passes for r in results) / world),
+                                    sum(r.stats.collide_passes for r in results) / world,
+                                    clock_of(name, results)),
                                 "hbm": hbm_view(deck, nx, variant, name, ev, K, same)})
             if variant == 2:
                 kernels.append({"name": "tile sort (count, scan, place, chunks) + collision queue",
@@ -696,11 +757,15 @@ def main():
                     for k in ("histories", "facets", "collisions", "census"):
                         lev[k] = lev[k] / world
                     alone = issue_roofline(deck, nx, variant, dom["name"], lev, K,
-                                           sum(r.stats.collide_passes for r in l_results) / world)
+                                           sum(r.stats.collide_passes for r in l_results) / world,
+                                           clock_of(dom["name"], l_results))
                     if alone:
                         roofline["alone"] = {
                             "frac": alone["frac"], "frac_low": alone["frac_low"], "frac_high": alone["frac_high"],
                             "frac_from_pass_count": alone.get("frac_from_pass_count"),
+                            "frac_bracket": alone.get("frac_bracket"),
+                            "shader_clock_ghz_measured": alone.get("shader_clock_ghz_measured"),
+                            "frac_at_measured_clock": alone.get("frac_at_measured_clock"),
                             "kernel_ms_avg": alone["kernel_ms_avg"],
                             "note": "same kernel, same run, second timed region (neutral_hip_set_lazy_export(1): no "
                                     "write-back pass runs beside it); in the headline region the write-back of the "

@@ -221,6 +221,10 @@ typedef struct {
                             the queue in proportion to what a wave is served (5 : 1 : 1 : 1 over
                             the four waves of a SIMD; 0: equal shares -- a small queue, a partial
                             grid) */
+  double stream_clock_ghz;  /* tiled variant: the shader clock the stream kernel and the collision */
+  double collide_clock_ghz; /* stage ran at, measured by one wave of every launch over its own life
+                               (shader-clock ticks per tick of the constant 100-MHz clock); 0: not
+                               measured.  The chip does not hold its nominal 2.4 GHz under every load */
 } NeutralHipStepStats;
 
 /* Number of visible devices (does not initialise a device context). */

@@ -618,6 +618,13 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
   g.last.steals = hc[0].nsteals + hc[1].nsteals;
   g.last.steals_refused = hc[0].steal_refused + hc[1].steal_refused;
   g.last.weighted_waves = hc[0].nweighted + hc[1].nweighted;
+  /* (this rank's own launches: the clocks are not summed over ranks) */
+  g.last.stream_clock_ghz = hc[0].clock_100mhz_ticks
+                                ? (double)hc[0].clock_shader_ticks / ((double)hc[0].clock_100mhz_ticks * 10.0)
+                                : 0.0;
+  g.last.collide_clock_ghz = hc[1].clock_100mhz_ticks
+                                 ? (double)hc[1].clock_shader_ticks / ((double)hc[1].clock_100mhz_ticks * 10.0)
+                                 : 0.0;
   g.last.stream_hops = tiled ? ctrl[10] : 0;
   g.last.stream_overflows = tiled ? ctrl[11] : 0;
   g.last.stream_batches = tiled ? ctrl[12] : 0;

@@ -360,7 +360,10 @@ void refresh_table_view(const NeutralHipCrossSection* cs_s, const NeutralHipCros
       }
     }
     v.fine = {nullptr, 0, 0, 0};
-    if (v.same && v.ix_s.start && g.variant == NEUTRAL_HIP_VARIANT_TILED) {
+    /* (NEUTRAL_NO_FINE_INDEX=1: experiments that need the collision stage's workgroups small in
+     * LDS -- 17 KB instead of 34 -- to sit beside another kernel's; read once per view) */
+    const char* no_fine = getenv("NEUTRAL_NO_FINE_INDEX");
+    if (v.same && v.ix_s.start && g.variant == NEUTRAL_HIP_VARIANT_TILED && !(no_fine && atoi(no_fine) != 0)) {
       const neutral::CsIndex fine =
           build_index(v.keys_s, v.n_s, g.d_index_fine, 43, kMaxFineIndexBuckets);
       if (fine.start && fine.shift < v.ix_s.shift) {

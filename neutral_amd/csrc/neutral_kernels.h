@@ -94,6 +94,14 @@ struct StepCounters {
                                        read from the hardware does not name one CU: see StealWork) */
   unsigned long long nweighted; /* collision stage: waves that were dealt a share in proportion to
                                    what a wave is served (SolveArgs::share_weight) */
+  /* The shader clock the kernel ran at, measured by one wave of every launch over its own
+   * life: ticks of the shader clock (s_memtime) and of the constant 100-MHz clock
+   * (s_memrealtime), summed over the step's launches.  The chip does not hold its nominal
+   * 2.4 GHz under every load (a kernel of nothing but v_fma_f64 runs at 1.85 GHz:
+   * profiles/r05/pmc_calibration.log), and a roofline in issue cycles needs the clock there was. */
+  unsigned long long clock_shader_ticks;
+  unsigned long long clock_100mhz_ticks;
+  unsigned long long clock_parked[2]; /* (the measuring wave's counters at its start) */
 };
 
 /* Device workspace of the collision stage's work stealing (neutral_kernels.hip): the control

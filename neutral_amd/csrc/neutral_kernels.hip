@@ -427,6 +427,9 @@ void history_regroup_kernel(SolveArgs a) {
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
   }
+  if (kQueue) {
+    clock_stamp_begin(cold_args().counters); /* (workgroup 0 is of the row that always works) */
+  }
   /* Collision stage, launched as many workgroups per CU as stay resident (a.occupancy_rows,
    * one wave of each per SIMD): how many of them work is decided HERE, from the queue
    * length the host has not seen yet.  A collider is a serial chain of ~10^3 collisions;
@@ -1011,6 +1014,9 @@ void history_regroup_kernel(SolveArgs a) {
     if (w_collide_passes) {
       atomicAdd(&a.counters->ncollide_passes, (unsigned long long)w_collide_passes);
     }
+  }
+  if (kQueue) {
+    clock_stamp_end(cold_args().counters);
   }
 }
 

@@ -59,7 +59,12 @@ namespace neutral {
 
 constexpr int kWindow = kWindowCells; /* cells per LDS window edge (neutral_history.h; 88 and
                                          two windows when the scalar flux is kept) */
-constexpr int kStreamBlock = 1024; /* 16 waves share one window */
+/* (-DNEUTRAL_STREAM_BLOCK=768: the build of the co-residency experiment of round 5 -- three waves
+ * per SIMD stream as fast as four, and leave a wave slot per SIMD to another kernel) */
+#ifndef NEUTRAL_STREAM_BLOCK
+#define NEUTRAL_STREAM_BLOCK 1024
+#endif
+constexpr int kStreamBlock = NEUTRAL_STREAM_BLOCK; /* 16 waves share one window */
 /* A chunk is what one workgroup takes at a time from one tile's particles: big
  * enough to amortise its two barriers and a window move, small enough that
  * every workgroup gets several (the host picks the size from the particle
@@ -888,6 +893,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   if (a.abort_flag && *a.abort_flag) {
     return; /* the cached view of the cs tables is stale: the host re-runs the step */
   }
+  clock_stamp_begin(a.counters);
   /* stage the cs index(es), zero the window */
   CsLookup<const unsigned short*> ix{nullptr, nullptr};
   {
@@ -1521,6 +1527,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
       if (w_census) atomicAdd(&a.counters->ncensus, (unsigned long long)w_census);
     }
   }
+  clock_stamp_end(a.counters);
 }
 
 /* ---- 2b. spatial domain decomposition: what moves between ranks ----------------------

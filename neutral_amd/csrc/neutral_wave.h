@@ -41,5 +41,25 @@ __device__ __forceinline__ void flush_counters(const SolveArgs& a, unsigned npro
   }
 }
 
+/* One wave of a launch (wave 0 of workgroup 0) measures the shader clock over its own life:
+ * clock_stamp_begin() at the kernel's entry parks the two counters in the launch's StepCounters
+ * record (nothing is held in registers), clock_stamp_end() before it leaves turns them into
+ * the two tick counts of StepCounters (added up over the launches of a step). */
+__device__ __forceinline__ bool clock_wave() { return blockIdx.x == 0 && (threadIdx.x >> 6) == 0; }
+__device__ __forceinline__ void clock_stamp_begin(StepCounters* c) {
+  if (clock_wave() && (threadIdx.x & 63) == 0) {
+    c->clock_parked[0] = __builtin_readcyclecounter();
+    c->clock_parked[1] = wall_clock64();
+  }
+}
+__device__ __forceinline__ void clock_stamp_end(StepCounters* c) {
+  if (clock_wave() && (threadIdx.x & 63) == 0) {
+    const unsigned long long shader = __builtin_readcyclecounter() - c->clock_parked[0];
+    const unsigned long long wall = wall_clock64() - c->clock_parked[1];
+    atomicAdd(&c->clock_shader_ticks, shader);
+    atomicAdd(&c->clock_100mhz_ticks, wall);
+  }
+}
+
 }  // namespace neutral
 #endif

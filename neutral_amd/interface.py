@@ -74,7 +74,8 @@ class StepStats(C.Structure):
                 ("stream_batches", C.c_uint64), ("stream_idle_polls", C.c_uint64),
                 ("local_nprocessed", C.c_uint64), ("exchange_ms", C.c_double),
                 ("exchange_rounds", C.c_int), ("emigrants", C.c_uint64),
-                ("weighted_waves", C.c_uint64)]
+                ("weighted_waves", C.c_uint64),
+                ("stream_clock_ghz", C.c_double), ("collide_clock_ghz", C.c_double)]
 
 
 # every symbol include/neutral_hip.h declares

@@ -56,6 +56,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bench", required=True)
     ap.add_argument("--source", required=True)
+    ap.add_argument("--share", type=int, default=None,
+                    help="the profiled run is the share one of this many ranks holds")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
     line = [ln for ln in open(a.bench).read().splitlines() if ln.startswith("{")][-1]
@@ -79,10 +81,20 @@ def main():
         e = {"deck": cfg["deck"], "nx": cfg["nx"], "variant": cfg["kernel_variant"],
              "kernel": name, "event": PRIMARY[name], "events_profiled": events,
              "nparticles_profiled": cfg["nparticles"], "steps_profiled": bench["steps"],
-             "dispatches_profiled": launches.get(name), "source": a.source, "per_event": per}
+             "dispatches_profiled": launches.get(name), "source": a.source, "per_event": per,
+             "kernel_ms_per_launch_same_flags": k.get("ms_per_launch")}
+        passes = ((k.get("valu_issue") or {}).get("collision_passes_per_launch") or 0) * bench["steps"]
+        if passes and "SQ_INSTS_VALU" in sums[name]:
+            # what a wave-level collision pass issues on average, refills and hand-backs included:
+            # the DYNAMIC counterpart of the static trip of tools/isa_histogram.py (which also counts
+            # the instructions of blocks a trip rarely enters)
+            e["valu_insts_per_collision_pass"] = sums[name]["SQ_INSTS_VALU"] / passes
+            e["collision_passes_profiled"] = passes
+        if a.share:
+            e["share_of"] = a.share   # (coefficients of a multi-GPU rank's share of the workload)
         table["entries"] = [x for x in table["entries"]
-                            if (x["deck"], x["nx"], x["variant"], x["kernel"]) !=
-                            (e["deck"], e["nx"], e["variant"], e["kernel"])]
+                            if (x["deck"], x["nx"], x["variant"], x["kernel"], x.get("share_of")) !=
+                            (e["deck"], e["nx"], e["variant"], e["kernel"], e.get("share_of"))]
         table["entries"].append(e)
         print(name, "events", events, {c: round(v, 4) for c, v in sorted(per.items())})
     json.dump(table, open(path, "w"), indent=1)

@@ -26,7 +26,9 @@ if [ $light = 0 ]; then
   pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum
   dirs="$dirs $out/pmc_l2"
 fi
-python3 $R/tools/pmc_events.py --bench $out/bench_profiled_flags.json \
+# (SHARE=N in the environment: the run is the share one of N ranks holds -- its coefficients are kept
+#  next to the whole workload's and priced into the N-GPU line)
+python3 $R/tools/pmc_events.py --bench $out/bench_profiled_flags.json ${SHARE:+--share $SHARE} \
   --source "tools/profile_bench.sh $tag: bench.py $P under rocprofv3 --pmc" $dirs | tee $out/pmc_per_event.log
 cp $R/profiles/pmc_per_event.json $out/pmc_per_event.json
 for f in $out/ktrace/*/*_kernel_stats.csv; do cp $f $out/kernel_stats.csv; done

@@ -27,6 +27,10 @@ shipped)
   bash tools/profile_bench.sh $tag/stream4000 --light --workload stream4000 --steps 4 --warmup 1
   bash tools/profile_bench.sh $tag/csp4000 --light --workload csp4000 --steps 10 --warmup 1
   ;;
+share)
+  # the coefficients of what an 8-GPU rank holds of the bench workload (priced into the N = 8 line)
+  SHARE=8 bash tools/profile_bench.sh $tag/share8 --light --nparticles 12500000 --steps 20 --warmup 5
+  ;;
 priced)
   # every workload's bench line again, priced with the coefficients committed by the parts above
   for w in "stream 10 1" "scatter 2 0" "split 1 0" "stream4000 4 1" "csp4000 10 1"; do
