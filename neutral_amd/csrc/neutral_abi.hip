@@ -375,7 +375,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       /* this step's records (t.rec_out until the swap below) to the SoA arrays */
       HIP_CHECK(neutral::launch_export_records(
           g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, a.abort_flag,
-          a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
+          a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr, 0xFFFFFFFFu,
+          nullptr, 0, a.export_skip_long_dead != 0));
     }
     HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
     /* (whatever else this step enqueues -- more passes for a step that outran its plan -- is
@@ -450,7 +451,8 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
         if (pass_export && !decomposed) {
           HIP_CHECK(neutral::launch_export_records(
               g.tiled.rec_out, g.tiled.slot_of_id, a.p, a.nparticles, g.stream, nullptr,
-              a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr));
+              a.export_skip_long_dead ? neutral::tiled_first_inactive(g.tiled) : nullptr, 0xFFFFFFFFu,
+              nullptr, 0, a.export_skip_long_dead != 0));
         }
         HIP_CHECK(hipEventRecord(g.ev_exported, g.stream));
         if (exchange) {

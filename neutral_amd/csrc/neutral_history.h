@@ -467,15 +467,26 @@ constexpr int kRecStateBits = 3;
  * particle fields to go on elsewhere (another pass, the collision stage, another
  * rank) with the stream it would have had: omp3/neutral.c:131,235,294 count up from 0
  * within a timestep. */
+/* ... and, in its top bit, whether the history changed direction, energy, weight or died in
+ * this timestep (a collision, a reflection): kRecChanged.  The write-back of a record without it
+ * leaves those fields of the interface's arrays alone -- they hold them already when the arrays
+ * were current as the step began -- and reads only the record's first 48 bytes.  A history
+ * carries the flag in the top bit of History::id while it is in the stream kernel's registers
+ * (kIdChanged: set by the reflection's rare branch, no register of its own in the facet loop). */
+constexpr int kRecChanged = (int)0x80000000u;
+constexpr unsigned kIdChanged = 0x80000000u;
 __device__ __forceinline__ int record_word(int state, unsigned counter) {
-  return state | (int)(counter << kRecStateBits);
+  return state | (int)((counter << kRecStateBits) & 0x7FFFFFFFu);
 }
 __device__ __forceinline__ int record_state(int word) { return word & ((1 << kRecStateBits) - 1); }
 __device__ __forceinline__ unsigned record_counter(int word) {
-  return (unsigned)word >> kRecStateBits;
+  return ((unsigned)word & 0x7FFFFFFFu) >> kRecStateBits;
 }
 
-__device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r) {
+/* keep_changed: the record's kRecChanged flag goes on with the history (a migrant of the stream
+ * kernel: the same timestep); otherwise it starts clean */
+__device__ __forceinline__ void load_record(History& h, const SolveArgs& a, const ParticleRec& r,
+                                            bool keep_changed = false) {
   h.x = r.x;
   h.y = r.y;
   h.omega_x = r.omega_x;
@@ -487,7 +498,7 @@ __device__ __forceinline__ void load_record(History& h, const SolveArgs& a, cons
   h.cellx = r.cellx;
   h.celly = r.celly;
   h.dead = 0;
-  h.id = r.id;
+  h.id = r.id | ((keep_changed && (r.dead & kRecChanged)) ? kIdChanged : 0u);
   h.counter = record_counter(r.dead); /* (prologue starts from 0 whatever this says) */
 }
 
@@ -558,7 +569,10 @@ typedef unsigned rec_quad __attribute__((ext_vector_type(4)));
 constexpr int kRecQuads = kParticleRecBytes / 16;
 
 /* the 80 bytes a record holds as five 16-byte quads (not the padding of an over-aligned one) */
-__device__ __forceinline__ void record_quads(const History& h, int state, rec_quad (&q)[kRecQuads]) {
+/* changed: the history's direction, energy or weight differ from what it began the timestep with,
+ * or it died (the collision stage: always; the stream kernel: History::id says) */
+__device__ __forceinline__ void record_quads(const History& h, int state, rec_quad (&q)[kRecQuads],
+                                             bool changed = false) {
   ParticleRec o;
   o.x = h.x;
   o.y = h.y;
@@ -570,15 +584,15 @@ __device__ __forceinline__ void record_quads(const History& h, int state, rec_qu
   o.mfp_to_collision = h.mfp_to_collision;
   o.cellx = h.cellx;
   o.celly = h.celly;
-  o.id = h.id;
-  o.dead = record_word(state, h.counter);
+  o.id = h.id & ~kIdChanged;
+  o.dead = record_word(state, h.counter) | ((changed || (h.id & kIdChanged)) ? kRecChanged : 0);
   __builtin_memcpy(q, &o, kParticleRecBytes); /* (registers to registers: no type punning) */
 }
 
 __device__ __forceinline__ void store_record(const History& h, const SolveArgs& a,
-                                             ParticleRec& r, int state) {
+                                             ParticleRec& r, int state, bool changed = false) {
   rec_quad q[kRecQuads];
-  record_quads(h, state, q);
+  record_quads(h, state, q, changed);
   rec_quad* dst = (rec_quad*)__builtin_assume_aligned(&r, 16);
 #pragma unroll
   for (int k = 0; k < kRecQuads; ++k) {
@@ -622,7 +636,7 @@ __device__ __forceinline__ void store_record_through(const History& h, const Sol
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ void load_record_through(History& h, const SolveArgs& a,
-                                                    const ParticleRec& r) {
+                                                    const ParticleRec& r, bool keep_changed = false) {
   rec_quad q[kRecQuads];
   asm volatile(
       "global_load_dwordx4 %0, %5, off sc1\n"
@@ -636,7 +650,7 @@ __device__ __forceinline__ void load_record_through(History& h, const SolveArgs&
       : "memory");
   ParticleRec o;
   __builtin_memcpy(&o, q, kParticleRecBytes);
-  load_record(h, a, o);
+  load_record(h, a, o, keep_changed);
 }
 
 /* ... together with the 16-byte side record that belongs to it (SuspendExtra): six loads, one wait */
@@ -1246,6 +1260,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
       h.omega_y = flip_y ? -h.omega_y : h.omega_y;
       h.u_y_inv = flip_y ? -h.u_y_inv : h.u_y_inv;
       if (reflect) {
+        h.id |= kIdChanged; /* (the direction is no longer what the arrays hold: kRecChanged) */
         /* turned round in the same cell: the other edge of it (a dependent load, here only) */
         aim_targets(h, a);
         double ex = edge_x<kComputedEdges>(a, h.target_ix);

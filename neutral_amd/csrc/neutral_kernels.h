@@ -32,11 +32,16 @@ struct ParticleView {
  * Sorted-by-tile access is random per particle, and a random 80-B record costs
  * two 64-B sectors where the SoA store costs eleven; the records are kept in
  * tile order from step to step and carry the particle id (the RNG key). */
+/* What a history that neither collides nor reflects changes comes FIRST (48 bytes: position, the
+ * two clocks, cell, id, state): the write-back of such a history reads those three quads -- one
+ * 64-byte sector for every other record instead of two -- and stores six fields, not eleven
+ * (export_records_kernel; the state word says whether direction, energy or weight changed). */
 struct alignas(16) ParticleRec {
-  double x, y, omega_x, omega_y, energy, weight, dt_to_census, mfp_to_collision;
+  double x, y, dt_to_census, mfp_to_collision;
   int cellx, celly;
   unsigned id; /* index in the SoA store = global id - pid_base */
-  int dead;
+  int dead;    /* the record's state word: neutral_history.h, record_word() */
+  double omega_x, omega_y, energy, weight;
 };
 constexpr int kParticleRecBytes = 80;
 static_assert(sizeof(ParticleRec) == kParticleRecBytes, "ParticleRec holds 80 bytes");
@@ -394,7 +399,8 @@ hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of
                                  const int* abort_flag = nullptr,
                                  const unsigned* first_inactive = nullptr,
                                  unsigned final_from = 0xFFFFFFFFu,
-                                 const unsigned* skip_ids = nullptr, int max_blocks = 0);
+                                 const unsigned* skip_ids = nullptr, int max_blocks = 0,
+                                 bool partial_ok = false);
 /* the write-back split in two (see TiledArgs::susp_ids): what launch_solve_tiled enqueues on a
  * stream of its own, beside the collision stage, when `on` */
 struct SplitExport {

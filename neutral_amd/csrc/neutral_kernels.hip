@@ -385,7 +385,7 @@ template <bool kQueue, bool kCarriesMicro = false>
 __device__ __forceinline__ void put_back(const History& h, const SolveArgs& a, int pid) {
   if (kQueue) {
     const int state = h.dead ? kRecDead : kRecIdle;
-    store_record(h, a, a.rec[pid], state);
+    store_record(h, a, a.rec[pid], state, true); /* (a history of this stage has collided) */
     a.slot_info[pid] = slot_summary(state, h.cellx - a.x_off, h.celly - a.y_off, a.tiles_x,
                                     a.tile_shift);
     if (kCarriesMicro && a.carried) {

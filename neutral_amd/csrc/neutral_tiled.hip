@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
                                                                     const int* abort_flag,
                                                                     const unsigned* first_inactive,
                                                                     unsigned final_from,
-                                                                    const unsigned* skip_ids) {
+                                                                    const unsigned* skip_ids,
+                                                                    int partial_ok) {
   if (abort_flag && *abort_flag) {
     return; /* the step's kernels have done nothing: rec holds an older step */
   }
@@ -544,20 +545,36 @@ __global__ __launch_bounds__(kSortBlock) void export_records_kernel(const Partic
       continue; /* dead since before the step began: the arrays have its final state, and the
                  random access to its record -- what this pass is bound by -- is saved */
     }
-    const ParticleRec r = rec[slot];
+    /* What every history changes sits in the record's first 48 bytes (ParticleRec): position, the
+     * two clocks, cell, state.  Direction, energy, weight and the death flag change only in a
+     * collision or a reflection, and the state word says whether one happened (kRecChanged): a
+     * record without it -- nine in ten in csp -- is written back from its first three quads (one
+     * 64-byte sector for every other record instead of two) into six of the eleven arrays; the other
+     * five hold what they should already.  partial_ok: the arrays were current as the step
+     * began (else every field is written). */
+    const rec_quad* const q = (const rec_quad*)__builtin_assume_aligned(&rec[slot], 16);
+    ParticleRec r;
+    rec_quad* const rq = (rec_quad*)&r;
+    rq[0] = q[0];
+    rq[1] = q[1];
+    rq[2] = q[2];
     /* (streamed out once: non-temporal stores keep them from evicting the half-read lines
      * of the records, -15 % on this pass: tools/micro/export_probe.hip) */
     __builtin_nontemporal_store(r.x, &p.x[k]);
     __builtin_nontemporal_store(r.y, &p.y[k]);
-    __builtin_nontemporal_store(r.omega_x, &p.omega_x[k]);
-    __builtin_nontemporal_store(r.omega_y, &p.omega_y[k]);
-    __builtin_nontemporal_store(r.energy, &p.energy[k]);
-    __builtin_nontemporal_store(r.weight, &p.weight[k]);
     __builtin_nontemporal_store(r.dt_to_census, &p.dt_to_census[k]);
     __builtin_nontemporal_store(r.mfp_to_collision, &p.mfp_to_collision[k]);
     __builtin_nontemporal_store(r.cellx, &p.cellx[k]);
     __builtin_nontemporal_store(r.celly, &p.celly[k]);
-    __builtin_nontemporal_store((record_state(r.dead) == kRecDead) ? 1 : 0, &p.dead[k]);
+    if (!partial_ok || (r.dead & kRecChanged)) {
+      rq[3] = q[3];
+      rq[4] = q[4];
+      __builtin_nontemporal_store(r.omega_x, &p.omega_x[k]);
+      __builtin_nontemporal_store(r.omega_y, &p.omega_y[k]);
+      __builtin_nontemporal_store(r.energy, &p.energy[k]);
+      __builtin_nontemporal_store(r.weight, &p.weight[k]);
+      __builtin_nontemporal_store((record_state(r.dead) == kRecDead) ? 1 : 0, &p.dead[k]);
+    }
   }
 }
 
@@ -1210,15 +1227,15 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             if (from_queue || (queues && !fresh)) {
               /* stored by another workgroup of this launch: around the L1 (neutral_history.h);
                * (a later pass's own migrants too: its lines' neighbours are changing hands) */
-              load_record_through(h, a, t.rec_out[src]);
+              load_record_through(h, a, t.rec_out[src], true);
               if (from_queue) {
                 const int want_tile = ((h.celly - a.y_off) >> t.tile_shift) * t.tiles_x + ((h.cellx - a.x_off) >> t.tile_shift);
                 /* (a record that does not belong to the queue it was taken from is a defect of
                  * the hand-off: reported and dropped, never streamed) */
-                bad_load = (want_tile != chunk_tile) | (!kDomain && h.id >= (unsigned)a.nparticles);
+                bad_load = (want_tile != chunk_tile) | (!kDomain && (h.id & ~kIdChanged) >= (unsigned)a.nparticles);
               }
             } else {
-              load_record(h, a, fresh ? t.rec_in[src] : t.rec_out[src]);
+              load_record(h, a, fresh ? t.rec_in[src] : t.rec_out[src], !fresh);
             }
             if (fresh) {
               /* who lives in the slot / where the particle lives: what the write-back (or a
@@ -1839,12 +1856,13 @@ bool tiled_uses_carried(const SolveArgs& a, const TiledArgs& t) {
 hipError_t launch_export_records(const ParticleRec* rec, const unsigned* slot_of_id,
                                  const ParticleView& p, int n, hipStream_t stream,
                                  const int* abort_flag, const unsigned* first_inactive,
-                                 unsigned final_from, const unsigned* skip_ids, int max_blocks) {
+                                 unsigned final_from, const unsigned* skip_ids, int max_blocks,
+                                 bool partial_ok) {
   if (n > 0) {
     int grid = (n + kSortBlock - 1) / kSortBlock;
     grid = (max_blocks > 0 && grid > max_blocks) ? max_blocks : grid;
     hipLaunchKernelGGL(export_records_kernel, dim3(grid), dim3(kSortBlock), 0, stream, rec,
-                       slot_of_id, p, n, abort_flag, first_inactive, final_from, skip_ids);
+                       slot_of_id, p, n, abort_flag, first_inactive, final_from, skip_ids, partial_ok ? 1 : 0);
   }
   return hipGetLastError();
 }
@@ -2013,7 +2031,7 @@ hipError_t launch_split_export(const SolveArgs& a, const TiledArgs& t, const Spl
   (void)hipStreamWaitEvent(split.side, after_collect, 0);
   (void)launch_export_records(t.rec_out, t.slot_of_id, split.p, a.nparticles, split.side, a.abort_flag,
                               split.skip_long_dead ? &t.ctrl[kCtrlFirstInactive] : nullptr, 0xFFFFFFFFu,
-                              t.susp_ids);
+                              t.susp_ids, 0, split.skip_long_dead != 0);
   (void)hipEventRecord(split.done, split.side);
   return hipGetLastError();
 }

@@ -113,6 +113,9 @@ static void fork_ranks(int nranks) {
   snprintf(buf, sizeof(buf), "%d", free_port());
   setenv("MASTER_ADDR", "127.0.0.1", 1);
   setenv("MASTER_PORT", buf, 1);
+  /* (the port that was just found free is the one the ranks meet on: left to its default --
+   * MASTER_PORT + 1, comms_ranks.c -- the rendezvous would listen on a port nobody has looked at) */
+  setenv("NEUTRAL_COMM_PORT", buf, 1);
   snprintf(buf, sizeof(buf), "%d", nranks);
   setenv("WORLD_SIZE", buf, 1);
   if (!getenv("NEUTRAL_COMM_NONCE")) {

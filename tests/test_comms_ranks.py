@@ -37,7 +37,8 @@ def launch(exe, nranks, extra_env=None):
     procs = []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_TIMEOUT="30")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_PORT=str(port),
+                   NEUTRAL_COMM_TIMEOUT="30")
         env.update(extra_env or {})
         procs.append(subprocess.Popen([exe], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
@@ -61,7 +62,7 @@ def test_without_a_launcher_there_is_one_rank(selftest):
 def test_a_missing_rank_is_an_error_not_a_hang(selftest):
     port = free_port()
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), NEUTRAL_COMM_TIMEOUT="2")
+               MASTER_PORT=str(port), NEUTRAL_COMM_PORT=str(port), NEUTRAL_COMM_TIMEOUT="2")
     out = subprocess.run([selftest], env=env, capture_output=True, text=True, timeout=60)
     assert out.returncode != 0
     assert "only 1 of 2 ranks arrived" in out.stderr
@@ -76,10 +77,10 @@ def test_strays_do_not_end_a_launch(selftest):
     import time
     port = free_port()
     env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               NEUTRAL_COMM_TIMEOUT="60")
+               NEUTRAL_COMM_PORT=str(port), NEUTRAL_COMM_TIMEOUT="60")
     rank0 = subprocess.Popen([selftest], env=dict(env, RANK="0", LOCAL_RANK="0"),
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    comm_port = port + 1          # (comms_ranks.c: NEUTRAL_COMM_PORT defaults to MASTER_PORT + 1)
+    comm_port = port              # (NEUTRAL_COMM_PORT: the port that was found free)
 
     def knock(payload):
         for _ in range(200):

@@ -35,7 +35,8 @@ def _run_ranks(deck, out, steps, px, py, mode="domain", extra=()):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_HIP_COMM="host",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_PORT=str(port),
+                   NEUTRAL_HIP_COMM="host",
                    NEUTRAL_HIP_QUIET="1", NEUTRAL_COMM_TIMEOUT="120",
                    NEUTRAL_WINDOW_MIN_PARTICLES="32", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen(

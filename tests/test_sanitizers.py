@@ -59,8 +59,8 @@ def test_rank_layer_under_asan_ubsan(tmp_path):
     procs = []
     for r in range(3):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3",
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_TIMEOUT="60",
-                   ASAN_OPTIONS="detect_leaks=1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_PORT=str(port),
+                   NEUTRAL_COMM_TIMEOUT="60", ASAN_OPTIONS="detect_leaks=1")
         procs.append(subprocess.Popen([exe], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     for r, p in enumerate(procs):

@@ -29,7 +29,8 @@ def test_sharded_ranks_reproduce_the_single_rank_run(make_problem, cs, tmp_path,
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_TIMEOUT="60")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NEUTRAL_COMM_PORT=str(port),
+                   NEUTRAL_COMM_TIMEOUT="60")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests",
                                                                     "shard_worker_cpu.py"),
                                        prob.deck, str(tmp_path)], env=env,

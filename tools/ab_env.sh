@@ -3,7 +3,7 @@
 #   tools/ab_env.sh OUTDIR "BENCH ARGS" "NAME=VALUE ..." "NAME=VALUE ..." ...   ("-" = nothing set)
 out=$1; shift; args=$1; shift
 mkdir -p $out
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   i=0
   for setting in "$@"; do
     i=$((i+1))

@@ -4,7 +4,7 @@
 # library runs twice, interleaved
 out=$1; shift; args=$1; shift
 mkdir -p $out
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for lib in "$@"; do
     if [ $lib = new ]; then unset NEUTRAL_HIP_LIB; else export NEUTRAL_HIP_LIB=neutral_amd/build/libneutral_hip_$lib.so; fi
     timeout -k 10 300 python bench.py $args --no-cpu-baseline > $out/ab_${lib}_$rep.json 2> $out/ab_${lib}_$rep.err || { tail -5 $out/ab_${lib}_$rep.err; exit 1; }
