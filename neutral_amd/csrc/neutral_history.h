@@ -601,15 +601,18 @@ __device__ __forceinline__ void store_record(const History& h, const SolveArgs& 
 }
 
 /* ---- records that change hands INSIDE a launch --------------------------------------
- * A record that another workgroup may pick up before the kernel ends (a migrant queued for
- * another tile's window in the stream kernel, a history handed back to a ring of the
- * collision stage that a CU-mate may take from) is stored WRITE-THROUGH (sc1: the bytes
+ * A record that ANOTHER WORKGROUP ON ANY XCD may pick up before the kernel ends (a migrant queued
+ * for another tile's window in the stream kernel) is stored WRITE-THROUGH (sc1: the bytes
  * leave this XCD's L2 for the memory side) and the storing wave waits for its stores
  * (drain_stores) BEFORE it publishes the record's number with an agent-scope atomic; whoever
  * picks the number up loads the record with sc1 loads, which bypass its CU's L1 (never
  * refreshed by other CUs' stores).  tools/micro/handoff_litmus.hip is this protocol on records
  * that share 128-byte lines with records other workgroups are rewriting at the same time, across
- * XCDs: 0 stale of 6.3e6 hops, where plain accesses see 1.6e6 (profiles/r04/experiments/). */
+ * XCDs: 0 stale of 6.3e6 hops, where plain accesses see 1.6e6 (profiles/r04/experiments/).
+ * (The collision stage's ring hand-backs are NOT this protocol: a ring is only taken from by
+ * waves of the same XCD -- the CU key carries the XCC id -- so the record is plain stores, drained
+ * before the ring's control word says it waits, and the thief's take ends in an agent-scope
+ * acquire before its plain loads: neutral_kernels.hip, try_steal.) */
 __device__ __forceinline__ void store_record_through(const History& h, const SolveArgs& a,
                                                      ParticleRec& r, int state) {
   rec_quad q[kRecQuads];
