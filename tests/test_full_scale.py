@@ -92,11 +92,26 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not gpu_available(), reason="needs a GPU")]
 
 
+_CAPSYS = None
+
+
 def _progress(msg):
-    """A line the runner sees while pytest holds stdout back (minutes pass between dots here)."""
-    sys.__stderr__.write(f"[full scale] {msg}\n")
-    sys.__stderr__.flush()
-    print(msg, flush=True)
+    """A line the runner sees while pytest holds the output back (minutes pass between dots
+    here): written with the capture switched off (pytest captures at the file-descriptor level,
+    so sys.__stderr__ is held back like everything else)."""
+    if _CAPSYS is not None:
+        with _CAPSYS.disabled():
+            print(f"[full scale] {msg}", flush=True)
+    else:
+        print(msg, flush=True)
+
+
+@pytest.fixture(autouse=True)
+def _uncaptured(capsys):
+    global _CAPSYS
+    _CAPSYS = capsys
+    yield
+    _CAPSYS = None
 
 
 TALLY_L2_TOL = 1e-9   # bar: 1e-6 (BASELINE.json north_star); floating state: 1e-9

@@ -451,6 +451,49 @@ def test_write_back_mode_can_change_between_steps(iface, make_problem, cs, deck,
         assert alive[3] < alive[2] and alive[4] < alive[3], alive
 
 
+@pytest.mark.parametrize("deck,nx,n,dt", [("csp", 128, 60000, 2.0e-6), ("stream", 200, 40000, None)])
+def test_carried_start_survives_steps_that_do_not_keep_it(iface, make_problem, cs, deck, nx, n, dt):
+    """The stream kernel starts histories from the cross section carried with each record's slot and
+    from the first draw the counting sort makes (neutral_history.h: prologue_carried) -- except in the
+    instantiations that look up and draw themselves (tile queues here).  A step of the second kind
+    keeps nothing of the carried values, so the library marks them stale and the next step of the
+    first kind looks them up afresh (refresh_micro_kernel) before it relies on them.  Tile queues
+    switched on and off between the steps of ONE store: the arrays and the event counts of the
+    over-particle kernel at every step, tallies to summation order."""
+    kw = dict(nx=nx, nparticles=n, iterations=6)
+    if dt is not None:
+        kw["dt"] = dt
+    prob = make_problem(deck, **kw)
+    pattern = (False, True, False, False, True, False)   # tile queues per step
+
+    def run(variant):
+        sim = iface.Simulation(prob, *cs, variant=variant)
+        sim.inject()
+        out = []
+        try:
+            for tt, queues in enumerate(pattern, start=1):
+                iface.set_stream_queues(queues and variant == 2)
+                r = sim.step(tt)
+                out.append(((r.nprocessed, r.facets, r.collisions, r.census), sim.particle_arrays(),
+                            r.stats.stream_hops))
+            tally = sim.tally_host()
+        finally:
+            iface.set_stream_queues(False)
+            sim.close()
+        return out, tally
+
+    want, want_t = run(0)
+    got, got_t = run(2)
+    for tt, ((ev0, a0, _), (ev2, a2, hops)) in enumerate(zip(want, got), start=1):
+        assert ev0 == ev2, tt
+        for f in a0:
+            assert np.array_equal(a0[f], a2[f]), (tt, f)
+    assert np.linalg.norm(want_t - got_t) <= 1e-13 * np.linalg.norm(want_t)
+    if deck == "stream":
+        # (the steps with queues did hand histories on inside the launch: they were the other kind)
+        assert got[1][2] > 0 and got[4][2] > 0 and got[0][2] == 0
+
+
 @pytest.mark.parametrize("deck,dt", [("scatter", None), ("split", 2.0e-8)])
 @pytest.mark.parametrize("lazy", [False, True])
 def test_the_dead_keep_their_slots_and_cost_nothing(iface, make_problem, cs, lazy, deck, dt):
