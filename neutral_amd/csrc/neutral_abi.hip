@@ -338,9 +338,14 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
     a.export_view = nullptr;
     g.tiled.mark_suspended = 0;
     if (split.on) {
-      g.h_export_view = a.p;
-      HIP_CHECK(hipMemcpyAsync(g.d_export_view, &g.h_export_view, sizeof(a.p), hipMemcpyHostToDevice,
-                               g.stream));
+      /* (the stepped store's eleven array pointers: uploaded when they change, not every step --
+       * a copy out of pageable host memory is a staging kernel of 70-130 us in the kernel trace) */
+      if (memcmp(&g.h_export_view, &a.p, sizeof(a.p)) != 0 || !g.export_view_uploaded) {
+        g.h_export_view = a.p;
+        HIP_CHECK(hipMemcpyAsync(g.d_export_view, &g.h_export_view, sizeof(a.p), hipMemcpyHostToDevice,
+                                 g.stream));
+        g.export_view_uploaded = true;
+      }
       HIP_CHECK(hipMemsetAsync(g.tiled.susp_ids, 0, sizeof(unsigned) * g.susp_id_words, g.stream));
       a.export_view = g.d_export_view;
       g.tiled.mark_suspended = 1;

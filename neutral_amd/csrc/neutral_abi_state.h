@@ -207,6 +207,7 @@ struct State {
   hipEvent_t ev_split_done = nullptr;
   neutral::ParticleView* d_export_view = nullptr; /* the stepped store's array pointers, for the */
   neutral::ParticleView h_export_view = {};        /* collision stage's own write-back */
+  bool export_view_uploaded = false;
   double suspended_share = -1.0;
   size_t susp_id_words = 0;
   neutral::LaunchTuning tuning = {}; /* read once per store (neutral_kernels.h) */

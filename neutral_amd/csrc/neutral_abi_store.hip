@@ -45,6 +45,7 @@ void ensure_scratch() {
     HIP_CHECK(hipStreamCreateWithPriority(&g.export_stream, hipStreamNonBlocking, least));
     HIP_CHECK(hipEventCreateWithFlags(&g.ev_split_done, hipEventDisableTiming));
     HIP_CHECK(hipMalloc((void**)&g.d_export_view, sizeof(neutral::ParticleView)));
+    g.export_view_uploaded = false;
   }
   if (!g.h_results) {
     HIP_CHECK(hipHostMalloc((void**)&g.h_results, sizeof(StepResults), hipHostMallocMapped));
