@@ -385,8 +385,12 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
     return; /* (an abandoned attempt leaves slot_of_id as the last finished step made it) */
   }
   const unsigned first_inactive = t.tile_offset[t.nsort];
-  const unsigned u = blockIdx.x * kSortBlock + threadIdx.x;
   const unsigned ncarried = (unsigned)t.sort_end - first_inactive;
+  /* (a grid of a few thousand workgroups strides over what there is to carry -- known on the
+   * device only -- instead of one workgroup per 256 particles of the store returning at once:
+   * 390 625 dispatches at 1e8) */
+  const unsigned total = ncarried + (unsigned)(t.mirror_end - t.sort_end);
+  for (unsigned u = blockIdx.x * kSortBlock + threadIdx.x; u < total; u += gridDim.x * kSortBlock) {
   if (u < ncarried) {
     const unsigned j = first_inactive + u;
     const unsigned src = t.order[j];
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(kSortBlock) void copy_inactive_kernel(SolveArgs a, 
       t.rec_out[m] = t.rec_in[m]; /* same slot: slot_of_id stays */
       t.info_out[m] = t.info_in[m];
     }
+  }
   }
 }
 
@@ -1885,8 +1890,8 @@ static hipError_t enqueue_stream_pass(const SolveArgs& a, TiledArgs& t, int pass
                      t);
   hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, stream, t);
   if (pass == 0) {
-    /* (grid sized for the worst case: no record takes part) */
-    hipLaunchKernelGGL(copy_inactive_kernel, dim3(grid_n), dim3(kSortBlock), 0, stream, a, t);
+    hipLaunchKernelGGL(copy_inactive_kernel, dim3(grid_n < 8192 ? grid_n : 8192), dim3(kSortBlock), 0, stream,
+                       a, t);
     if (after_sort) {
       (void)hipEventRecord(after_sort, stream);
     }
