@@ -294,10 +294,10 @@ void solve_transport_2d(const int nx, const int ny, const int global_nx, const i
       /* the tally window takes 128 KB of the 160 KB of LDS: an index that does
        * not fit next to it stays in HBM-side bisection (same brackets) */
       const size_t lds_limit = 160 * 1024 - 64;
-      if (neutral::tiled_lds_bytes(a) > lds_limit) {
+      if (neutral::tiled_lds_bytes(a, g.tiled) > lds_limit) {
         a.absorb_index = nullptr;
       }
-      if (neutral::tiled_lds_bytes(a) > lds_limit) {
+      if (neutral::tiled_lds_bytes(a, g.tiled) > lds_limit) {
         a.scatter_index = nullptr;
       }
     }

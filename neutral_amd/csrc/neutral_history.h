@@ -122,9 +122,18 @@ typedef GlobalTallyT<false> GlobalTally;
 typedef __attribute__((address_space(3))) double lds_double;
 
 /* window edge in cells: one 128 x 128 window (128 KB) fills the LDS next to the cs
- * index; two windows of 88 x 88 (121 KB) take its place when the flux is kept */
+ * index; two windows of 88 x 88 (121 KB) take its place when the flux is kept -- of 100 x 100
+ * (158 KB) in the stream kernel's instantiations that stage no index (histories start from
+ * carried values: neutral_tiled.hip, kCarried), where the LDS is the windows' alone */
 constexpr int kWindowCells = 128;
 constexpr int kWindowCellsWithFlux = 88;
+#ifndef NEUTRAL_FLUX_WINDOW_NO_INDEX
+#define NEUTRAL_FLUX_WINDOW_NO_INDEX 100 /* (A/B: 88 is the window beside an index) */
+#endif
+constexpr int kWindowCellsWithFluxNoIndex = NEUTRAL_FLUX_WINDOW_NO_INDEX;
+__host__ __device__ constexpr int window_cells(bool with_flux, bool no_index) {
+  return with_flux ? (no_index ? kWindowCellsWithFluxNoIndex : kWindowCellsWithFlux) : kWindowCells;
+}
 /* A row of the window in LDS is this many cells longer than the window is wide: with rows of
  * exactly 128 cells (1 KB) the cells of one COLUMN share an LDS bank, and the histories a wave
  * streams together sit in a patch of neighbouring cells -- rows apart as often as columns
@@ -134,12 +143,12 @@ constexpr int kWindowCellsWithFlux = 88;
 #endif
 constexpr int kWindowRowPad = NEUTRAL_WINDOW_ROW_PAD;
 
-template <bool kWithFlux>
+template <bool kWithFlux, bool kNoIndex = false>
 struct WindowTallyT {
   static constexpr bool kFlux = kWithFlux;
   static constexpr bool kUniformDensity = false;
   __device__ __forceinline__ bool inside() const { return false; }
-  static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
+  static constexpr int W = window_cells(kWithFlux, kNoIndex);
   static constexpr int S = W + kWindowRowPad; /* cells per row in LDS */
   lds_double* window; /* LDS, W rows of S, row-major (flux: the next W rows) */
   int ox;         /* local cell coordinates of window element (0,0) */
@@ -171,7 +180,7 @@ struct WindowTallyT {
 /* The same destination for a cell whose window coordinates the caller has already
  * worked out (the stream kernel needs them anyway, to decide whether a particle
  * that left the window should wait for the next pass). */
-template <bool kWithFlux, bool kUniform = false>
+template <bool kWithFlux, bool kUniform = false, bool kNoIndex = false>
 struct WindowCellTallyT {
   static constexpr bool kFlux = kWithFlux;
   /* kUniform: the density of every cell of the window, and of the cells around it, is the
@@ -181,7 +190,7 @@ struct WindowCellTallyT {
    * follows it -- the one load of the facet loop whose result the next trip waits for.
    * The stream kernel compiles its facet loop for both kinds of window. */
   static constexpr bool kUniformDensity = kUniform;
-  static constexpr int W = kWithFlux ? kWindowCellsWithFlux : kWindowCells;
+  static constexpr int W = window_cells(kWithFlux, kNoIndex);
   static constexpr int S = W + kWindowRowPad; /* cells per row in LDS */
   lds_double* window;
   unsigned lx, ly; /* cell - window origin; >= W outside the window */

@@ -377,7 +377,7 @@ hipError_t launch_tables_check(const double* ks, const double* vs, int ns, const
 
 
 /* tiled pipeline: sort by tile, stream with the LDS tally window, then K2 */
-size_t tiled_lds_bytes(const SolveArgs& a, bool carried = false);
+size_t tiled_lds_bytes(const SolveArgs& a, const TiledArgs& t);
 /* SoA store <-> record store (ids 0..n-1 in order on import; scatter by id on export) */
 hipError_t launch_import_records(const ParticleView& p, ParticleRec* rec, unsigned* info,
                                  unsigned* slot_of_id, unsigned* ids, int tiles_x, int tile_shift,

@@ -889,11 +889,11 @@ extern "C" void neutral_hip_debug_phase_clock(unsigned long long* out8) {
  * loop: profiles/r04/experiments/queue_policy_ab.log) */
 template <bool kSameTables, bool kFlux, bool kDomain, bool kChecked, bool kQueues>
 __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, TiledArgs t) {
-  constexpr int kW = WindowTallyT<kFlux>::W; /* window edge; kWindows of them in LDS */
-  constexpr int kWindows = kFlux ? 2 : 1;
   /* histories start from carried values (neutral_history.h: prologue_carried; the launcher sees
    * to it that they are valid: tiled_uses_carried): no lookup, no draw, no index in LDS */
   constexpr bool kCarried = kCarriedStart && kSameTables && !kDomain && !kQueues;
+  constexpr int kW = WindowTallyT<kFlux, kCarried>::W; /* window edge; kWindows of them in LDS */
+  constexpr int kWindows = kFlux ? 2 : 1;
   extern __shared__ double lds_raw[];
   constexpr int kWindowDoubles = kW * (kW + kWindowRowPad); /* a window in LDS: kW rows (neutral_history.h) */
   double* window = lds_raw;                                             /* kWindows of them */
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
   int cur_tile = -1; /* tile the LDS window is centred on (holds its partial sums) */
   int win_ox = 0;
   int win_oy = 0;
-  WindowTallyT<kFlux> tally{(lds_double*)window, 0, 0};
+  WindowTallyT<kFlux, kCarried> tally{(lds_double*)window, 0, 0};
 
   unsigned nfacets = 0;     /* per lane */
   unsigned w_processed = 0; /* per wave (uniform) */
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
            * facet" -- before the first trip for the cell the history starts in -- so a trip
            * has one place where lanes leave, and the window coordinates of the new cell are
            * worked out once: for that question and for the next trip's tally. */
-          WindowCellTallyT<kFlux, kUniform> cell_tally{
+          WindowCellTallyT<kFlux, kUniform, kCarried> cell_tally{
               tally.window, (unsigned)(h.cellx - a.x_off - tally.ox),
               (unsigned)(h.celly - a.y_off - tally.oy), 0ull};
           bool out_of_window = cell_tally.outside();
@@ -1766,9 +1766,22 @@ hipError_t launch_export_by_slot(const ParticleRec* rec, const ParticleView& p, 
 
 /* ---- launcher ---------------------------------------------------------------------- */
 
-size_t tiled_lds_bytes(const SolveArgs& a, bool carried) {
-  const int cells = a.flux_tally ? 2 * kWindowCellsWithFlux * (kWindowCellsWithFlux + kWindowRowPad)
-                                 : kWindow * (kWindow + kWindowRowPad);
+/* does the stream kernel these arguments select stage the cs index in LDS?  (the kernel's
+ * kCarried, a compile-time property of the instantiation: same tables, one rank's whole mesh,
+ * no tile queues -- whether or not this step's carried values are valid) */
+static bool stream_stages_no_index(const SolveArgs& a, const TiledArgs& t) {
+  return kCarriedStart && a.same_tables && !a.decomposed && !t.queue_entries;
+}
+
+/* edge of the stream kernel's tally window(s) in cells */
+static int stream_window_cells(const SolveArgs& a, const TiledArgs& t) {
+  return window_cells(a.flux_tally != nullptr, stream_stages_no_index(a, t));
+}
+
+size_t tiled_lds_bytes(const SolveArgs& a, const TiledArgs& t) {
+  const int w = stream_window_cells(a, t);
+  const int cells = (a.flux_tally ? 2 : 1) * w * (w + kWindowRowPad);
+  const bool carried = stream_stages_no_index(a, t);
   return (carried ? stream_lds_payload_bytes<true, false>(a, cells)
                   : a.same_tables ? stream_lds_payload_bytes<true>(a, cells)
                                   : stream_lds_payload_bytes<false>(a, cells)) +
@@ -1962,7 +1975,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   /* (plan.stream_passes is what the step before needed, plus one) */
   t.stream_repeat = (plan.stream_passes <= 2) ? kStreamRepeatOnePass : kStreamRepeat;
   t.carried = tiled_uses_carried(a, t) ? 1 : 0;
-  const size_t lds = tiled_lds_bytes(a, t.carried != 0);
+  const size_t lds = tiled_lds_bytes(a, t);
   (void)hipFuncSetAttribute((const void*)tile_scatter_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(2 * sizeof(unsigned) * kSortLdsBins));
@@ -1972,7 +1985,7 @@ hipError_t launch_solve_tiled(const SolveArgs& a, TiledArgs& t, hipStream_t stre
   }
   if (first_pass == 0 && t.tile_uniform && a.pad == 0) {
     hipLaunchKernelGGL(tile_uniform_kernel, dim3(t.ntiles), dim3(kSortBlock), 0, stream, a, t,
-                       a.flux_tally ? kWindowCellsWithFlux : kWindow);
+                       stream_window_cells(a, t));
   } else if (first_pass == 0 && t.tile_uniform) {
     /* (a padded mesh is not checked: no window of it counts as uniform, whatever an earlier
      * step of another mesh left in the flags) */
