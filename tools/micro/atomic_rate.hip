@@ -23,12 +23,16 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
 // mode 0: one shared array; mode 1: copy per XCD; mode 2: shared array, neighbouring cells per lane
 // (a particle track: consecutive adds of a lane go to adjacent cells); mode 3: the flush pattern
 // of an LDS tally window -- the 64 lanes of a wave add to 64 CONSECUTIVE cells (one 512-B row
-// segment per wave instruction), segments at random rows
+// segment per wave instruction), segments at random rows; mode 4: copy per XCD with atomics of
+// WORKGROUP scope (no sc1: may the XCD's own L2 perform them?); mode 5: the same, wavefront scope;
+// mode 6: copy per XCD, workgroup scope, 64-cell row segments; mode 7: shared array, eight lanes
+// per 64-byte line, the wave's eight lines at random places (what a write-combining flush of
+// per-history line buffers would issue)
 template <int kMode>
 __global__ __launch_bounds__(256) void scatter_add(double* tally, unsigned ncells, int iters, unsigned* xcc_seen) {
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
   double* base = tally;
-  if (kMode == 1) {
+  if (kMode == 1 || kMode >= 4) {
     const unsigned x = xcc_id();
     base = tally + (size_t)x * ncells;
     if (threadIdx.x == 0) atomicOr(xcc_seen, 1u << x);
@@ -37,14 +41,24 @@ __global__ __launch_bounds__(256) void scatter_add(double* tally, unsigned ncell
   for (int i = 0; i < iters; ++i) {
     if (kMode == 2) {
       cell = (cell + 1 < ncells) ? cell + 1 : 0;
-    } else if (kMode == 3) {
+    } else if (kMode == 3 || kMode == 6) {
       const unsigned wave = tid >> 6;
       const unsigned seg = hash32(wave * 0x9e3779b9u + (unsigned)i) % (ncells / 64);
       cell = seg * 64 + (tid & 63);
+    } else if (kMode == 7) {
+      const unsigned group = tid >> 3;
+      const unsigned line = hash32(group * 0x9e3779b9u + (unsigned)i * 0x85ebca6bu) % (ncells / 8);
+      cell = line * 8 + (tid & 7);
     } else {
       cell = hash32(cell + 0x9e3779b9u * (unsigned)i + tid) % ncells;
     }
-    unsafeAtomicAdd(&base[cell], 1.0);
+    if (kMode == 4 || kMode == 6) {
+      __hip_atomic_fetch_add(&base[cell], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (kMode == 5) {
+      __hip_atomic_fetch_add(&base[cell], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+      unsafeAtomicAdd(&base[cell], 1.0);
+    }
   }
 }
 
@@ -84,6 +98,10 @@ int main() {
     if (run("copy per XCD, random cells", scatter_add<1>, tally, n, 8, d_seen, blocks, iters)) return 1;
     if (run("shared array, track of cells", scatter_add<2>, tally, n, 1, d_seen, blocks, iters)) return 1;
     if (run("shared array, 64-cell row segments", scatter_add<3>, tally, n, 1, d_seen, blocks, iters)) return 1;
+    if (run("shared array, 8 lanes per random line", scatter_add<7>, tally, n, 1, d_seen, blocks, iters)) return 1;
+    if (run("copy per XCD, workgroup scope", scatter_add<4>, tally, n, 8, d_seen, blocks, iters)) return 1;
+    if (run("copy per XCD, wavefront scope", scatter_add<5>, tally, n, 8, d_seen, blocks, iters)) return 1;
+    if (run("copy per XCD, wg scope, row segments", scatter_add<6>, tally, n, 8, d_seen, blocks, iters)) return 1;
     CHECK(hipFree(tally));
   }
   return 0;
