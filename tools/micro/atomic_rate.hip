@@ -32,7 +32,7 @@ template <int kMode>
 __global__ __launch_bounds__(256) void scatter_add(double* tally, unsigned ncells, int iters, unsigned* xcc_seen) {
   const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
   double* base = tally;
-  if (kMode == 1 || kMode >= 4) {
+  if (kMode == 1 || (kMode >= 4 && kMode != 7)) {
     const unsigned x = xcc_id();
     base = tally + (size_t)x * ncells;
     if (threadIdx.x == 0) atomicOr(xcc_seen, 1u << x);
