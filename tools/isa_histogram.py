@@ -32,10 +32,10 @@ TARGETS = {
     # kDomain=0, kCarryTargets=1, kComputedEdges=1, WindowCellTallyT<flux=0, uniform=0|1>>
     "facet": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
               "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-              r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb0EEE"),
+              r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb0ELb1EEE"),
     "facet_uniform": ("neutral_tiled-hip-amdgcn-amd-amdhsa-gfx950.s",
                       "_ZN7neutral13stream_kernelILb1ELb0ELb0ELb0ELb0EEEvNS_9SolveArgsENS_9TiledArgsE",
-                      r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb1EEE"),
+                      r"v_mul_f64", 12, r"cross_facetILb0ELb1ELi0ELb1ELb1ENS_16WindowCellTallyTILb0ELb1ELb1EEE"),
 }
 
 # Issue cycles one wave64 instruction holds its SIMD for, by opcode, measured with
