@@ -54,6 +54,9 @@ struct History {
   /* stream kernel only (see refined_reciprocal): reciprocals of speed and cell_mfp
    * for the two quotients of a facet crossing, and whether each may be used */
   double r_speed, r_cell_mfp;
+  /* stream kernel only: what a unit of path length deposits, ready for the tally -- weight,
+   * the two heating factors, the number density and 1/N in one factor (deposit_rate below) */
+  double dep_rate;
   int plain_div; /* bit 0: speed, bit 1: cell_mfp inside the plain division range */
   /* stream kernel only: the two coordinates the history aims at (facet_target of its cell's
    * edges and its direction).  A streaming history keeps its direction from facet to facet,
@@ -107,6 +110,10 @@ struct GlobalTallyT {
     const int cellx = pcellx - a.x_off;
     const int celly = pcelly - a.y_off;
     unsafeAtomicAdd(mesh_element(a.tally, celly * a.nx + cellx), energy_deposition * a.inv_ntotal_particles);
+  }
+  /* (a contribution that carries its 1/N already: deposit_rate) */
+  __device__ __forceinline__ void scaled(const SolveArgs& a, int pcellx, int pcelly, double v) const {
+    unsafeAtomicAdd(mesh_element(a.tally, (pcelly - a.y_off) * a.nx + (pcellx - a.x_off)), v);
   }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
                                        double track_length) const {
@@ -171,6 +178,10 @@ struct WindowTallyT {
                                              double energy_deposition) const {
     add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
   }
+  /* (a contribution that carries its 1/N already: deposit_rate) */
+  __device__ __forceinline__ void scaled(const SolveArgs& a, int pcellx, int pcelly, double v) const {
+    add(a, pcellx, pcelly, v, 0u, a.tally);
+  }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
                                        double track_length) const {
     add(a, pcellx, pcelly, track_length * a.inv_ntotal_particles, 1u, a.flux_tally);
@@ -231,6 +242,9 @@ struct WindowCellTallyT {
   __device__ __forceinline__ void operator()(const SolveArgs& a, int pcellx, int pcelly,
                                              double energy_deposition) const {
     add(a, pcellx, pcelly, energy_deposition * a.inv_ntotal_particles, 0u, a.tally);
+  }
+  __device__ __forceinline__ void scaled(const SolveArgs& a, int pcellx, int pcelly, double v) const {
+    add(a, pcellx, pcelly, v, 0u, a.tally);
   }
   __device__ __forceinline__ void flux(const SolveArgs& a, int pcellx, int pcelly,
                                        double track_length) const {
@@ -436,6 +450,19 @@ __device__ __forceinline__ void refresh_deposition_terms(History& h) {
 /* omp3/neutral.c:493-494 */
 __device__ __forceinline__ double deposit(const History& h, double path_length) {
   return h.weight * path_length * h.dep_sigma * h.dep_heat * h.number_density;
+}
+
+/* The stream kernel's form of the same estimator.  Between two collisions only the path length
+ * of :493-494's product changes (and the number density, where a facet leads into another
+ * density), so the product of everything else -- and of the 1/N update_tallies multiplies by
+ * (:414-416) -- is formed once, when the history starts and where its density changes, and a
+ * facet deposits path_length * dep_rate: one multiplication per facet for five.  This is the ONE
+ * place where the path departs from the reference's association order: the TALLY's value moves
+ * in its last bits (a relative 1e-16 per contribution, on a sum whose order the atomics do not
+ * fix either; bar: 1e-9 per cell against the oracle, 1e-12 against the stream deck's closed form),
+ * no particle's state and no event count can -- nothing reads the tally back. */
+__device__ __forceinline__ double deposit_rate(const History& h, const SolveArgs& a) {
+  return h.weight * h.dep_sigma * h.dep_heat * h.number_density * a.inv_ntotal_particles;
 }
 
 __device__ __forceinline__ void load_particle(History& h, const SolveArgs& a, int pid) {
@@ -1232,7 +1259,7 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     /* the stream kernel: nothing is pending in the accumulator (every facet flushes it and
      * collisions happen elsewhere; prologue() and resume() start it at zero), and 0 + d is d:
      * the accumulator stays out of the facet loop's registers */
-    tally(a, h.cellx, h.celly, deposit(h, distance_to_facet));
+    tally.scaled(a, h.cellx, h.celly, distance_to_facet * h.dep_rate); /* (deposit_rate) */
   } else {
     h.energy_deposition += deposit(h, distance_to_facet);
     tally(a, h.cellx, h.celly, h.energy_deposition);
@@ -1330,6 +1357,9 @@ __device__ __forceinline__ void cross_facet(History& h, const SolveArgs& a, cons
     if (kCachedReciprocals) {
       refresh_mfp_reciprocal<kChecked>(h);
     }
+    if (kCarryTargets) {
+      h.dep_rate = deposit_rate(h, a); /* (the number density is one of its factors) */
+    }
   }
 }
 
@@ -1342,6 +1372,22 @@ __device__ __forceinline__ void census(History& h, const SolveArgs& a, const Tal
   h.mfp_to_collision -= quotient_of_physical<kChecked>(distance_to_census, h.cell_mfp);
   h.energy_deposition += deposit(h, distance_to_census);
   tally(a, h.cellx, h.celly, h.energy_deposition);
+  if (Tally::kFlux) {
+    tally.flux(a, h.cellx, h.celly, h.track_length + h.weight * distance_to_census);
+    h.track_length = 0.0;
+  }
+  h.dt_to_census = 0.0;
+}
+
+/* census_event for the stream kernel: nothing is pending in the accumulator (every facet
+ * flushes it, collisions happen elsewhere), and the deposit is path length x dep_rate */
+template <bool kChecked, typename Tally>
+__device__ __forceinline__ void census_streamed(History& h, const SolveArgs& a, const Tally& tally) {
+  const double distance_to_census = h.distance;
+  h.x += distance_to_census * h.omega_x;
+  h.y += distance_to_census * h.omega_y;
+  h.mfp_to_collision -= quotient_of_physical<kChecked>(distance_to_census, h.cell_mfp);
+  tally.scaled(a, h.cellx, h.celly, distance_to_census * h.dep_rate);
   if (Tally::kFlux) {
     tally.flux(a, h.cellx, h.celly, h.track_length + h.weight * distance_to_census);
     h.track_length = 0.0;

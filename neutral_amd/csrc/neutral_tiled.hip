@@ -1277,6 +1277,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
             h.plain_div = 0;
             refresh_speed_reciprocal<kChecked>(h); /* no collision here: the speed stays */
             refresh_mfp_reciprocal<kChecked>(h);
+            h.dep_rate = deposit_rate(h, a); /* ... and so do the weight and the heating factors */
             /* (wave-uniform branch: computed or loaded, the same bits) */
             if (edges_computed) {
               load_targets<true>(h, a);
@@ -1417,7 +1418,7 @@ __global__ __launch_bounds__(kStreamBlock) void stream_kernel(SolveArgs a, Tiled
           PHASE(3);
         } else {
           if (h.ev == kEvCensus) {
-            census<kChecked>(h, a, tally);
+            census_streamed<kChecked>(h, a, tally);
           }
           /* kEvEnd: the loop at omp3/neutral.c:134 exits */
           /* (a plain store: nobody picks this record up again in this launch.  Records that
