@@ -197,8 +197,10 @@ typedef struct {
                             its ring took half of what waited in the ring of a wave of its CU */
   uint64_t steals_refused; /* ... waves that would have taken but did not, because the key
                             that tells them who shares their CU (read from the hardware)
-                            collected more waves than a CU holds in this launch: the launch
-                            then steals nothing (0 on an MI355X) */
+                            collected more than twice the waves a CU holds in this launch
+                            (workgroups placed late enter themselves on a CU whose first ones
+                            have left: that much is expected): the launch then steals nothing
+                            (0 on an MI355X) */
   uint64_t stream_hops;  /* tiled variant: histories that left the tally window of the tile they
                             were streaming under with far to go and were handed, INSIDE the stream
                             kernel, to the queue of the tile they had reached (no further pass) */

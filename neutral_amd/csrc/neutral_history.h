@@ -429,6 +429,29 @@ __device__ __forceinline__ void refresh_direction(History& h) {
   h.u_y_inv = 1.0 / (h.omega_y * h.speed); /*  division; a select around the plain one: +-0) */
 }
 
+/* The same two reciprocals after a collision in the fast arithmetic policy: where no lane's
+ * cosine is (nearly) zero -- the product of the two cosines, each at most 1 in magnitude, is at
+ * least 2^-150, so omega * speed lies in [2^-187, 2^101] for every speed of the proven range --
+ * the division's wrapping (v_div_scale / v_div_fmas / v_div_fixup) is the identity and the
+ * refined reciprocal with its one correction delivers the bits of 1.0 / (omega * speed)
+ * (neutral_device.h: quotient_by_reciprocal; 14 operations for 24).  Asked of the wave: a
+ * cosine of exactly zero, a NaN (a scattering cosine that rounding pushed past 1: :266) or
+ * anything else outside sends every lane through the wrapped divisions above. */
+__device__ __forceinline__ void refresh_direction_plain_or_wrapped(History& h) {
+  const double both = h.omega_x * h.omega_y;
+  const unsigned hi = (unsigned)__double2hiint(both) & 0x7FFFFFFFu;
+  const bool plain = (hi - ((1023u - 150u) << 20)) < (200u << 20); /* 2^-150 <= |both| < 2^50 */
+  if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+    const double ux = h.omega_x * h.speed;
+    const double uy = h.omega_y * h.speed;
+    h.u_x_inv = quotient_by_reciprocal(1.0, ux, refined_reciprocal(ux));
+    h.u_y_inv = quotient_by_reciprocal(1.0, uy, refined_reciprocal(uy));
+  } else {
+    asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
+    refresh_direction(h);
+  }
+}
+
 /* the energy- and table-dependent factors of calculate_energy_deposition
  * (omp3/neutral.c:481-494); deposit() below finishes the product */
 template <bool kSameTables, bool kChecked>
@@ -917,6 +940,27 @@ __device__ __forceinline__ bool next_is_collision(History& h, const CellEdges& e
          (distance_to_collision < distance_to_census);
 }
 
+/* Surely yes?  The same answer without the distance to the facet.  The way to an edge of the
+ * cell ALONG the history's direction is at least the perpendicular distance to the nearest of the
+ * four edges (a direction cosine is at most 1 in magnitude; the open lower bound lies beyond the
+ * lower edge), so a collision closer than HALF of that -- the half covers the few ulps of the
+ * computed quotients and of a cosine that rounding pushed past 1 -- comes before any facet: where
+ * this says yes, next_is_collision() says yes, for every input of the fast arithmetic policy
+ * (no NaN, no infinity among the operands: a history outside its cell by rounding has a negative
+ * distance to an edge and is not sure).  Four differences, three minima and a sum where the
+ * facet's distance is two direction tests, eight selects, two differences and six products --
+ * and in a dense block the collision is ten million times closer than the edge.  h.distance is
+ * the distance to the collision, as next_is_collision() leaves it. */
+__device__ __forceinline__ bool surely_next_is_collision(History& h, const CellEdges& e) {
+  const double distance_to_collision = h.mfp_to_collision * h.cell_mfp;
+  const double distance_to_census = h.speed * h.dt_to_census;
+  const double nearest = __builtin_fmin(__builtin_fmin(h.x - e.x_lo, e.x_hi - h.x),
+                                        __builtin_fmin(h.y - e.y_lo, e.y_hi - h.y));
+  h.distance = distance_to_collision;
+  return (h.dt_to_census > 0.0) & (distance_to_collision + distance_to_collision < nearest) &
+         (distance_to_collision < distance_to_census);
+}
+
 /* loop head for a history that carries its targets (stream kernel): no edge loads here */
 __device__ __forceinline__ void decide_carried(History& h) {
   const bool running = (h.dt_to_census > 0.0);
@@ -1112,7 +1156,11 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   }
   h.dt_to_census -= quotient_of_physical<kChecked>(distance_to_collision, h.speed);
   h.speed = speed_of<kChecked>(h.energy);
-  refresh_direction(h);
+  if (kChecked) {
+    refresh_direction(h);
+  } else {
+    refresh_direction_plain_or_wrapped(h);
+  }
   refresh_deposition_terms<kSameTables, kChecked>(h);
   return died;
 }

@@ -115,7 +115,12 @@ struct StepCounters {
  * is reset by one kernel on the launch's own stream before every collision stage. */
 constexpr int kRingCtlSlots = 8192;  /* waves of a launch (4 096 on an MI355X) */
 constexpr int kCuSlots = 4096;       /* (xcc 4 bits, se 3, sh 1, cu 4) */
-constexpr int kCuWavesMax = 16;
+/* (16 waves of a launch are resident on a CU at a time, but a key can collect more over a launch's
+ * life: the write-back pass that starts beside the collision stage may hold wave slots when the
+ * stage's workgroups are placed, the ones left over are placed when a slot frees up -- also on a
+ * CU whose first workgroups have gone through their small shares and left, where they are the
+ * fifth to enter themselves.  Twice a CU's waves: a key that collects more does not name a CU) */
+constexpr int kCuWavesMax = 32;
 struct StealWork {
   unsigned long long ring_ctl[kRingCtlSlots]; /* head << 32 | waiting */
   /* waves that are reading entries out of a ring they have just taken from: the owner waits

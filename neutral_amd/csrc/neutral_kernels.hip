@@ -301,8 +301,10 @@ constexpr unsigned kRequeued = 0x80000000u; /* ring entry flag: SuspendExtra is 
  *       - every successful take is followed by an agent-scope acquire (the thief's L1 holds
  *         nothing stale of the records and ring words it is about to read: the CU bits of the
  *         key may be wrong, the take is still right);
- *       - a key that collects more than kCuWavesMax waves does not name one CU (the decode is
- *         wrong on this part, or the launch is not the shape the lists assume): the launch
+ *       - a key that collects more than kCuWavesMax waves -- twice what a CU holds at a time:
+ *         workgroups placed late enter themselves where the first ones have left (neutral_kernels.h)
+ *         -- does not name one CU (the decode is wrong on this part, or the launch is not the
+ *         shape the lists assume): the launch
  *         then steals nothing (StealWork::overfull; counted in StepCounters::steal_refused
  *         and NeutralHipStepStats::steals_refused);
  *       - an owner does not write into its ring while anybody reads from it (ring_readers).
@@ -897,7 +899,16 @@ void history_regroup_kernel(SolveArgs a) {
             want = kWantRefill;
           } else if (kQueue) {
             /* (the chain goes on, or -- rarely -- its end gets a name) */
-            if (next_is_collision(h, edges, x_lo_open, y_lo_open)) {
+            /* Asked of the wave first in the form that needs no facet distance: where every
+             * colliding lane is surely at another collision -- all but one pass in a million
+             * in a dense block -- the exact comparisons are not made at all */
+            bool goes_on;
+            if (!kChecked && __builtin_expect(__ballot(!surely_next_is_collision(h, edges)) == 0ull, 1)) {
+              goes_on = true;
+            } else {
+              goes_on = next_is_collision(h, edges, x_lo_open, y_lo_open);
+            }
+            if (goes_on) {
               h.ev = kEvCollision;
             } else {
               next_event_after_collision();

@@ -175,7 +175,8 @@ def test_weighted_shares_at_test_size(iface, make_problem, cs, monkeypatch, deck
     assert max(s.weighted_waves for s in got[3]) >= 4000, [s.weighted_waves for s in got[3]]
     assert sum(s.steals for s in got[3]) > 100
     assert sum(s.requeued for s in got[3]) > 0
-    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3])
+    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3]), \
+        [(s.aborted, s.steals_refused, s.steals, s.weighted_waves, s.suspended) for s in got[3]]
     monkeypatch.setenv("NEUTRAL_SHARE_WEIGHT", "1")
     equal = _run(iface, prob, cs, 2, steps)
     _same(want, equal)
@@ -198,7 +199,8 @@ def test_a_slow_thief_is_waited_for(iface, make_problem, cs, monkeypatch):
     _same(want, got)
     assert sum(s.steals for s in got[3]) > 50
     assert sum(s.requeued for s in got[3]) > 0
-    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3])
+    assert all(s.aborted == 0 and s.steals_refused == 0 for s in got[3]), \
+        [(s.aborted, s.steals_refused, s.steals, s.weighted_waves, s.suspended) for s in got[3]]
 
 
 def test_two_stores_stepped_in_turn_on_two_streams(iface, make_problem, cs, monkeypatch):
