@@ -835,7 +835,11 @@ __device__ __forceinline__ void start_carried(History& h, const SolveArgs& a, do
   h.energy_deposition = 0.0;
   h.track_length = 0.0;
   h.nevents = 0;
-  refresh_direction(h);
+  if (kChecked) {
+    refresh_direction(h);
+  } else {
+    refresh_direction_plain_or_wrapped(h); /* (same bits: asked of the wave's starting lanes) */
+  }
   refresh_deposition_terms<true, kChecked>(h);
 }
 
