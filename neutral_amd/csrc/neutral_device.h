@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "neutral_log_table.h"
+
 namespace neutral {
 
 /* neutral_data.h:17-24 */
@@ -202,7 +204,7 @@ __device__ __forceinline__ double quotient_of_physical(double a, double b); /* b
  * Every division, square root and logarithm of the event bodies exists in two forms
  * that deliver the same bits wherever both are defined:
  *   kChecked = false  the bare operation sequences (refined reciprocal + three
- *                     operations, rsq + Goldschmidt, the 42-instruction log) with no
+ *                     operations, rsq + Goldschmidt, the table-driven log) with no
  *                     range test, exact for operands in the PROVEN RANGE below;
  *   kChecked = true   IEEE operations on any operand: a range test in front of each
  *                     fast sequence and the compiler's own division / sqrt / log behind
@@ -308,18 +310,15 @@ __device__ __forceinline__ double sqrt_of_physical(double x) {
 /* ---- log of a sample (omp3/neutral.c:131,295: mfp = -log(rn)/Sigma_s) -----------
  * The device library's log() delivers a double-double result internally (it also
  * serves pow) and costs ~95 vector instructions; a collision draws one log and is
- * bound by vector issue.  This is the classical faithful evaluation in ~42:
- *     x = 2^k * m, m in [sqrt(1/2), sqrt(2)),  f = m - 1,  s = f / (2 + f),  z = s^2
- *     log(1+f) = 2s + s*R(z),  R(z) = sum_{j=1..10} 2/(2j+1) z^j   (|s| <= 0.1716: the
- *                                      truncated tail is below 2^-60 of the result)
- *     log(x)   = k*ln2_hi - ((f^2/2 - (s*(f^2/2 + R) + k*ln2_lo)) - f)
- * with ln2 split so that k*ln2_hi is exact.  Error below 1 ulp (measured on the
- * device against an 80-bit reference: tests/test_hip_parity.py), like the libm the
- * reference links -- the log is the one operation of this path that is NOT
- * identical between conforming math libraries, and event counts have never
- * depended on its last bit (section 3 of DESIGN.md).  Samples lie in [2^-65, 1];
- * zero, negative, subnormal, infinite and NaN arguments get log()'s answers from a
- * rare branch. */
+ * bound by vector issue.  Rounds 1-4 used the classical division-based evaluation
+ * (s = f / (2 + f), ten Horner steps in s^2: 42 instructions and a reciprocal, 0.8 ulp);
+ * log_core() below is the table-driven form that replaced it (21 instructions, two
+ * loads, 0.51 ulp).  Error below 1 ulp (measured on the device against an 80-bit
+ * reference: tests/test_hip_parity.py), like the libm the reference links -- the log is
+ * the one operation of this path that is NOT identical between conforming math
+ * libraries, and event counts have never depended on its last bit (section 3 of
+ * DESIGN.md).  Samples lie in [2^-65, 1]; zero, negative, subnormal, infinite and NaN
+ * arguments get log()'s answers from a rare branch. */
 __device__ __forceinline__ double refined_reciprocal(double b);                           /* below */
 __device__ __forceinline__ double quotient_by_reciprocal(double a, double b, double r); /* below */
 
@@ -335,36 +334,42 @@ __device__ __forceinline__ double horner_step(double r, double z, double c) {
 }
 
 __device__ __forceinline__ double log_core(double x, int k_scaled) {
-  double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
-  int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
-  const bool low = (m < 0.70710678118654752440);
-  m = low ? m + m : m; /* [sqrt(1/2), sqrt(2)) */
-  k = low ? k - 1 : k;
-  const double f = m - 1.0; /* exact */
-  /* (f is +0 or 1e-16 ... 0.41 in magnitude, 2 + f is 1.7 ... 2.41: plain operands whatever
-   * the sample was, so both arithmetic policies share this form) */
-  const double denom = 2.0 + f;
-  const double s = quotient_by_reciprocal(f, denom, refined_reciprocal(denom));
-  const double z = s * s;
-  /* (Horner steps through horner_step(): left to itself the compiler turns r = fma(r, z, c)
-   * into v_mov_b64 tmp, c; v_fmac_f64 tmp, r, z -- a 4-cycle register copy per step in a
+  /* Round 5: by table.  x = 2^k m, m in [1/2, 1); the entry of m's top eight fraction bits holds
+   * r, a multiple of 1/64 with |m r - 1| <= 2^-6.9, and -log r in two parts (neutral_log_table.h,
+   * tools/gen_log_table.py).  f = fma(m, r, -1) is EXACT (m r is a multiple of 2^-59 below
+   * 2^-6 in magnitude), so
+   *     log x = (k ln2_hi - log r|hi) + (f + (f^2 Q(f) + (k ln2_lo - log r|lo)))
+   * with Q the series of (log(1+f) - f) / f^2 to f^6 (the tail is below 2^-65), the first sum
+   * exact (both terms are multiples of 2^-32 below 64) and f joined to it by a two-sum: 0.51 ulp
+   * at worst on the 2.5 million samples of tests/test_hip_parity.py (0.25 on average; the
+   * division-based form it replaces: 0.8), 21 vector instructions and two table loads for 42 and
+   * a reciprocal.  Just below one (m >= 127/128) r is 1 and the result is log1p of the exact
+   * m - 1; at a power of two f is 0 and the two parts of -log 2 cancel k's exactly: log(1) = +0. */
+  const double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
+  const int k = __builtin_amdgcn_frexp_exp(x) + k_scaled;
+  const unsigned entry = ((unsigned)__double2hiint(m) >> 12) & 0xFFu;
+  const double* const e = kLogTable + 4u * entry;
+  const double r = e[0];
+  const double l_hi = e[1];
+  const double l_lo = e[2];
+  const double f = __builtin_fma(m, r, -1.0);
+  /* (Horner steps through horner_step(): left to itself the compiler turns q = fma(q, f, c)
+   * into v_mov_b64 tmp, c; v_fmac_f64 tmp, q, f -- a 4-cycle register copy per step in a
    * kernel that is bound by vector issue -- where v_fma_f64 takes c as a third operand) */
-  double r = 2.0 / 21.0;
-  r = horner_step(r, z, 2.0 / 19.0);
-  r = horner_step(r, z, 2.0 / 17.0);
-  r = horner_step(r, z, 2.0 / 15.0);
-  r = horner_step(r, z, 2.0 / 13.0);
-  r = horner_step(r, z, 2.0 / 11.0);
-  r = horner_step(r, z, 2.0 / 9.0);
-  r = horner_step(r, z, 2.0 / 7.0);
-  r = horner_step(r, z, 2.0 / 5.0);
-  r = horner_step(r, z, 2.0 / 3.0);
-  r = r * z;
-  const double hfsq = 0.5 * f * f;
+  double q = -1.0 / 8.0;
+  q = horner_step(q, f, 1.0 / 7.0);
+  q = horner_step(q, f, -1.0 / 6.0);
+  q = horner_step(q, f, 1.0 / 5.0);
+  q = horner_step(q, f, -1.0 / 4.0);
+  q = horner_step(q, f, 1.0 / 3.0);
+  q = __builtin_fma(q, f, -0.5); /* (an inline constant) */
   const double dk = (double)k;
-  constexpr double ln2_hi = 0.6931471803691238;     /* 0x3fe62e42fee00000: 32 significant bits */
-  constexpr double ln2_lo = 1.9082149292705877e-10; /* ln 2 - ln2_hi */
-  return dk * ln2_hi - ((hfsq - (s * (hfsq + r) + dk * ln2_lo)) - f);
+  const double hi = __builtin_fma(dk, kLogLn2Hi, l_hi); /* exact */
+  const double lo = __builtin_fma(dk, kLogLn2Lo, l_lo);
+  const double t = __builtin_fma(f * f, q, lo);
+  const double s = hi + f;
+  const double err = (hi - s) + f; /* (|hi| >= |f| or hi == 0: the two-sum's short form) */
+  return s + (err + t);
 }
 
 /* any argument: zero, negative, subnormal, infinite and NaN get log()'s answers */
