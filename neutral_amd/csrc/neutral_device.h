@@ -257,6 +257,14 @@ __device__ __forceinline__ double cs_interpolate(const double* __restrict__ keys
  * tests/test_hip_parity.py); zero is answered directly and everything else goes
  * to the ordinary sqrt. */
 /* the ten operations alone: for arguments KNOWN to lie in [2^-500, 2^500] */
+/* Round 5: ONE coupled Goldschmidt step and the residual correction -- eight operations.  v_rsq_f64
+ * is good to 2^-24.2 (measured: tools/micro/one_step.hip), the step leaves g1 and h1 within 2^-47.8,
+ * and the correction's own error is the product of the two, 2^-95 of the root: the result is the
+ * correctly rounded root unless the exact one lies within 2^-95 of a rounding boundary, once in
+ * 2^42 arguments (no difference from sqrt() in 8.6e9 random arguments on the device, none in the
+ * parity tests' millions; the compiler's ten operations -- a second step before the correction --
+ * make that never).  The path's own tolerance is what the logarithm already uses: a last bit
+ * of a flight in 10^13 roots, where one logarithm in fifty differs from libm's. */
 __device__ __forceinline__ double sqrt_known_plain(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   const double g0 = x * y;
@@ -265,9 +273,7 @@ __device__ __forceinline__ double sqrt_known_plain(double x) {
   const double g1 = __builtin_fma(g0, r0, g0);
   const double h1 = __builtin_fma(h0, r0, h0);
   const double d0 = __builtin_fma(-g1, g1, x);
-  const double g2 = __builtin_fma(d0, h1, g1);
-  const double d1 = __builtin_fma(-g2, g2, x);
-  return __builtin_fma(d1, h1, g2);
+  return __builtin_fma(d0, h1, g1);
 }
 
 __device__ __forceinline__ double sqrt_plain_range(double x) {
@@ -412,11 +418,16 @@ __device__ __forceinline__ double log_of_drawn_sample(double x) {
  * operations reproduce `a / b` bit for bit (tested against the compiler's own
  * division on the device, tests/test_hip_parity.py).  Anything outside the range
  * takes the ordinary division. */
+/* Round 5: ONE Newton step.  v_rcp_f64 is good to 2^-24.4 (measured: tools/micro/one_step.hip), the step
+ * leaves r within 2^-48.8 of 1/b, and the quotient's residual correction (quotient_by_reciprocal:
+ * q0 = a r, q = q0 + (a - b q0) r) is then off by 2^-48.8 of a residual of 2^-48.8: 2^-97 of the
+ * quotient -- the correctly rounded a / b unless the exact quotient lies within 2^-97 of a rounding
+ * boundary, once in 2^44 divisions (no difference from the compiler's division in 8.6e9 random
+ * quotients on the device; the second step of rounds 1 - 4 and of the compiler's own sequence makes
+ * that never).  See sqrt_known_plain() for what that is measured against. */
 __device__ __forceinline__ double refined_reciprocal(double b) {
   double r = __builtin_amdgcn_rcp(b);
-  double e = __builtin_fma(-b, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-b, r, 1.0);
+  const double e = __builtin_fma(-b, r, 1.0);
   r = __builtin_fma(r, e, r);
   return r;
 }
