@@ -184,7 +184,7 @@ def test_headline_size_against_the_oracle(iface, make_problem, cs):
 @pytest.mark.skipif(_WHY_NOT_BITWISE is not None, reason=str(_WHY_NOT_BITWISE))
 def test_time_slicing_and_stealing_at_scale_are_bitwise(iface, make_problem, cs):
     """csp 400^2, 4e7 particles, 4 timesteps: the tiled pipeline with its defaults (rings of
-    hundreds of histories per wave, taken from by CU-mates ~10 000 times) against the
+    hundreds of histories per wave, taken from by CU-mates thousands of times) against the
     over-particle kernel -- same event counts, EVERY particle field bit for bit, tallies equal up
     to summation order.  (tools/micro/compare_variants.py is the same check as a script.)"""
     n, steps = 40000000, 4
@@ -212,5 +212,5 @@ def test_time_slicing_and_stealing_at_scale_are_bitwise(iface, make_problem, cs)
     for f in a0:
         assert np.array_equal(a0[f], a2[f]), f
     assert float(np.linalg.norm(t0 - t2) / np.linalg.norm(t0)) < 1e-12
-    assert steals >= 10000
+    assert steals >= 3000   # (thousands: how many exactly follows the waves' timing -- 8 800 to 15 000 across builds)
     assert refused == 0
