@@ -18,9 +18,15 @@ def key(e):
 
 path = os.path.join(ROOT, "profiles", "pmc_per_event.json")
 table = {key(e): e for e in json.load(open(path))["entries"]}
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "**", "pmc_per_event.json"), recursive=True)):
+# (every part's file is the committed table plus ITS new entries -- and the committed table may hold entries of the
+#  same tag from an earlier run of the round: a file only contributes the entries made in its own directory,
+#  "<tag>:" at the top, "<tag>/<dir>:" below)
+top = os.path.join(ROOT, "gpurun_out", tag)
+for f in sorted(glob.glob(os.path.join(top, "**", "pmc_per_event.json"), recursive=True)):
+    sub = os.path.relpath(os.path.dirname(f), top)
+    own = f" {tag}:" if sub == "." else f" {tag}/{sub}:"
     for e in json.load(open(f))["entries"]:
-        if f" {tag}" in e.get("source", "") or f"{tag}/" in e.get("source", ""):
+        if own in e.get("source", ""):
             table[key(e)] = e
 out = {"entries": sorted(table.values(), key=lambda e: (e["deck"], e["nx"], e["kernel"], e.get("share_of") or 0))}
 json.dump(out, open(path, "w"), indent=1)
