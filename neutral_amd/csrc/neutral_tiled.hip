@@ -57,8 +57,8 @@
 
 namespace neutral {
 
-constexpr int kWindow = kWindowCells; /* cells per LDS window edge (neutral_history.h; 88 and
-                                         two windows when the scalar flux is kept) */
+/* (cells per LDS window edge: window_cells() in neutral_history.h -- 128; two windows of 88 or 100 with the
+ * scalar flux) */
 /* (-DNEUTRAL_STREAM_BLOCK=768: the build of the co-residency experiment of round 5 -- three waves
  * per SIMD stream as fast as four, and leave a wave slot per SIMD to another kernel) */
 #ifndef NEUTRAL_STREAM_BLOCK
