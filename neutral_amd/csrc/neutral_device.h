@@ -484,6 +484,44 @@ __device__ __forceinline__ double quotient_of_physical_by_constant(double a, dou
   }
   return quotient_by_reciprocal(a, b, y);
 }
+/* ---- the cosine of the laboratory scattering angle (omp3/neutral.c:263-265) ---------------
+ *     0.5 * ((A + 1) * sqrt(e_new / e) - (A - 1) * sqrt(e / e_new))
+ * Two quotients and two roots of arguments that are each other's reciprocals to an ulp
+ * (e_new / e in [0.96, 1.04]).  The fast policy seeds the second of each from the first instead
+ * of from the quarter-rate instructions, and the seeds are BETTER than those give:
+ *   q1 = e_new / e        refined reciprocal of e and the residual correction, as everywhere;
+ *   s1 = sqrt(q1)         v_rsq_f64, one coupled step (g1, h1 within 2^-47.8), the correction;
+ *   q2 = e / e_new        starts from (2 h1)^2 = 1/q1 within 2^-46 and takes its reciprocal of
+ *                         e_new from (1/e) (2 h1)^2: the residual correction is then within 2^-92;
+ *   s2 = sqrt(q2)         starts from g = q2 s1 -- s1 is 1/sqrt(q2) to 2^-52 -- and takes the
+ *                         correction alone: within 2^-104.
+ * Each is the IEEE result unless the exact one lies that close to a rounding boundary (as
+ * refined_reciprocal / sqrt_known_plain: once in 2^39 and more; tools/micro/scatter_cosine.hip
+ * counts no difference from the IEEE evaluation in 8.6e9 random scatters).  23 operations and two
+ * quarter-rate seeds for 28 and four. */
+template <bool kChecked>
+__device__ __forceinline__ double scatter_cosine(double e, double e_new) {
+  if (kChecked) {
+    return 0.5 * ((kMassNo + 1.0) * sqrt_plain_range(e_new / e) - (kMassNo - 1.0) * sqrt_plain_range(e / e_new));
+  }
+  const double r_e = refined_reciprocal(e);
+  const double q1 = quotient_by_reciprocal(e_new, e, r_e);
+  const double y = __builtin_amdgcn_rsq(q1);
+  const double g0 = q1 * y;
+  const double h0 = 0.5 * y;
+  const double r0 = __builtin_fma(-h0, g0, 0.5);
+  const double g1 = __builtin_fma(g0, r0, g0);
+  const double h1 = __builtin_fma(h0, r0, h0);
+  const double s1 = __builtin_fma(__builtin_fma(-g1, g1, q1), h1, g1);
+  const double t = h1 + h1; /* 1 / sqrt(q1) */
+  const double q2_seed = t * t;
+  const double r_e_new = r_e * q2_seed;
+  const double q2 = __builtin_fma(__builtin_fma(-e_new, q2_seed, e), r_e_new, q2_seed);
+  const double g = q2 * s1;
+  const double s2 = __builtin_fma(__builtin_fma(-g, g, q2), 0.5 * s1, g);
+  return 0.5 * ((kMassNo + 1.0) * s1 - (kMassNo - 1.0) * s2);
+}
+
 struct ByParticleMass {};
 struct ByMassNoPlusOneSquared {};
 constexpr double kMassNoPlusOneSquared = (kMassNo + 1.0) * (kMassNo + 1.0);

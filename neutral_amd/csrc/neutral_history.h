@@ -1117,11 +1117,7 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   const double e_new = absorbed ? h.energy : e_scattered;
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
   if (!absorbed) {
-    const double cos_theta =
-        0.5 * ((kMassNo + 1.0) *
-                   sqrt_of_physical<kChecked>(quotient_of_physical<kChecked>(e_new, h.energy)) -
-               (kMassNo - 1.0) *
-                   sqrt_of_physical<kChecked>(quotient_of_physical<kChecked>(h.energy, e_new)));
+    const double cos_theta = scatter_cosine<kChecked>(h.energy, e_new);
     const double sin_theta = sqrt_of_sine_squared<kChecked>(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);

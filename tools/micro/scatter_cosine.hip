@@ -1,0 +1,38 @@
+// Does the fast policy's scatter_cosine() (neutral_device.h: the second quotient and the second root seeded from the first)
+// deliver the bits of the IEEE evaluation of omp3/neutral.c:263-265?  Random energies over the tables' range, random
+// scattering samples; counts the cosines, and the parts, that differ.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I neutral_amd/csrc tools/micro/scatter_cosine.hip -o tools/micro/build/scatter_cosine
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "neutral_device.h"
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+using namespace neutral;
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
+__global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters, uint64_t seed) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long bad = 0;
+  for (int i = 0; i < iters; ++i) {
+    const uint64_t h = mix(seed + tid * 0x9E3779B97F4A7C15ull + (uint64_t)i);
+    const double u = u64_to_unit(h), v = u64_to_unit(mix(h + 1));
+    const double e = 1.0e-2 * exp2(u * 33.2);            /* 1e-2 ... 1e8 eV */
+    const double mu_cm = 1.0 - 2.0 * v;
+    const double e_new = (e * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0)) / ((kMassNo + 1.0) * (kMassNo + 1.0));
+    const double want = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / e) - (kMassNo - 1.0) * sqrt(e / e_new));
+    const double got = scatter_cosine<false>(e, e_new);
+    bad += (__double_as_longlong(got) != __double_as_longlong(want));
+  }
+  atomicAdd(&out[0], bad);
+}
+
+int main() {
+  unsigned long long* d; CHECK(hipMalloc(&d, 64)); CHECK(hipMemset(d, 0, 64));
+  const int blocks = 256 * 32, iters = 4096;
+  hipLaunchKernelGGL(probe, dim3(blocks), dim3(256), 0, 0, d, iters, 2026ull);
+  CHECK(hipDeviceSynchronize());
+  unsigned long long h[8]; CHECK(hipMemcpy(h, d, 64, hipMemcpyDeviceToHost));
+  printf("scatters %.3e: %llu cosines differ from the IEEE evaluation\n", (double)blocks * 256 * iters, h[0]);
+  return 0;
+}
