@@ -499,9 +499,13 @@ __device__ __forceinline__ double quotient_of_physical_by_constant(double a, dou
  * refined_reciprocal / sqrt_known_plain: once in 2^39 and more; tools/micro/scatter_cosine.hip
  * counts no difference from the IEEE evaluation in 8.6e9 random scatters).  23 operations and two
  * quarter-rate seeds for 28 and four. */
+/* (root_ratio = sqrt(e_new / e) and inv_root_ratio = 1 / sqrt(e_new / e) to 2^-47: what the
+ * speed after the scatter starts from, speed_after_scatter() below; fast policy only) */
 template <bool kChecked>
-__device__ __forceinline__ double scatter_cosine(double e, double e_new) {
+__device__ __forceinline__ double scatter_cosine(double e, double e_new, double& root_ratio,
+                                                 double& inv_root_ratio) {
   if (kChecked) {
+    root_ratio = inv_root_ratio = 0.0; /* (not used) */
     return 0.5 * ((kMassNo + 1.0) * sqrt_plain_range(e_new / e) - (kMassNo - 1.0) * sqrt_plain_range(e / e_new));
   }
   const double r_e = refined_reciprocal(e);
@@ -519,6 +523,8 @@ __device__ __forceinline__ double scatter_cosine(double e, double e_new) {
   const double q2 = __builtin_fma(__builtin_fma(-e_new, q2_seed, e), r_e_new, q2_seed);
   const double g = q2 * s1;
   const double s2 = __builtin_fma(__builtin_fma(-g, g, q2), 0.5 * s1, g);
+  root_ratio = s1;
+  inv_root_ratio = t;
   return 0.5 * ((kMassNo + 1.0) * s1 - (kMassNo - 1.0) * s2);
 }
 
@@ -563,6 +569,20 @@ __device__ __forceinline__ double speed_of(double energy) {
   /* omp3/neutral.c:117,297 */
   return sqrt_of_physical<kChecked>(quotient_of_physical_by_constant<ByParticleMass, kChecked>(
       2.0 * energy * kEvToJ, kParticleMass, 1.0 / kParticleMass));
+}
+
+/* The speed after a scatter (omp3/neutral.c:297), fast policy: its argument 2 E' eV / m is the old
+ * one times e_new / e to a few ulps, so the old speed times sqrt(e_new / e) -- both in hand -- is
+ * the new root to 2^-51, and half the old speed's reciprocal (the one the flight time has just
+ * been divided with) times 1 / sqrt(e_new / e) is 1 / (2 root) to 2^-46: the residual correction
+ * alone leaves 2^-97 (see sqrt_known_plain(); tools/micro/scatter_cosine.hip counts the speeds that
+ * differ from sqrt() of the same argument too).  Five operations for a quarter-rate seed and seven. */
+__device__ __forceinline__ double speed_after_scatter(double e_new, double speed, double r_speed,
+                                                      double root_ratio, double inv_root_ratio) {
+  const double arg = quotient_by_reciprocal(2.0 * e_new * kEvToJ, kParticleMass, 1.0 / kParticleMass);
+  const double g = speed * root_ratio;
+  const double h = (0.5 * r_speed) * inv_root_ratio;
+  return __builtin_fma(__builtin_fma(-g, g, arg), h, g);
 }
 
 /* inside [2^-100, 2^100]: what the fast arithmetic policy is proven on (the comment at the

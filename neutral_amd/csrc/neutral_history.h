@@ -1116,14 +1116,28 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
       1.0 / kMassNoPlusOneSquared);
   const double e_new = absorbed ? h.energy : e_scattered;
   const CsSearch search = lookup_cs_begin<kSameTables>(a, ix, e_new);
+  /* the flight to the collision took distance / speed of the speed it was flown at (:296):
+   * taken off here, ahead of the scatter that changes the speed -- and starts the new one from
+   * this reciprocal */
+  double r_speed_before = 0.0;
+  if (kChecked) {
+    h.dt_to_census -= distance_to_collision / h.speed;
+  } else {
+    r_speed_before = refined_reciprocal(h.speed);
+    h.dt_to_census -= quotient_by_reciprocal(distance_to_collision, h.speed, r_speed_before);
+  }
   if (!absorbed) {
-    const double cos_theta = scatter_cosine<kChecked>(h.energy, e_new);
+    double root_ratio, inv_root_ratio;
+    const double cos_theta = scatter_cosine<kChecked>(h.energy, e_new, root_ratio, inv_root_ratio);
     const double sin_theta = sqrt_of_sine_squared<kChecked>(1.0 - cos_theta * cos_theta);
     const double omega_x_new = (h.omega_x * cos_theta - h.omega_y * sin_theta);
     const double omega_y_new = (h.omega_x * sin_theta + h.omega_y * cos_theta);
     h.omega_x = omega_x_new;
     h.omega_y = omega_y_new;
     h.energy = e_new;
+    /* (:297; an absorbed history keeps its energy, hence its speed: the same bits) */
+    h.speed = kChecked ? speed_of<true>(e_new)
+                       : speed_after_scatter(e_new, h.speed, r_speed_before, root_ratio, inv_root_ratio);
   }
 
   /* the draw for the next free flight (:293-295) needs nothing from the tables: it
@@ -1154,8 +1168,6 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
     macroscopic_from_micro<false>(h); /* the density, hence number_density, has not changed (:289) */
     h.mfp_to_collision = minus_log_rn0 / h.macro_s; /* (-0.0 for a sample of exactly 1) */
   }
-  h.dt_to_census -= quotient_of_physical<kChecked>(distance_to_collision, h.speed);
-  h.speed = speed_of<kChecked>(h.energy);
   if (kChecked) {
     refresh_direction(h);
   } else {

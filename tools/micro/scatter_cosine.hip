@@ -13,7 +13,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51a
 
 __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters, uint64_t seed) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long bad = 0;
+  unsigned long long bad = 0, bad_speed = 0;
   for (int i = 0; i < iters; ++i) {
     const uint64_t h = mix(seed + tid * 0x9E3779B97F4A7C15ull + (uint64_t)i);
     const double u = u64_to_unit(h), v = u64_to_unit(mix(h + 1));
@@ -21,10 +21,17 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters,
     const double mu_cm = 1.0 - 2.0 * v;
     const double e_new = (e * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0)) / ((kMassNo + 1.0) * (kMassNo + 1.0));
     const double want = 0.5 * ((kMassNo + 1.0) * sqrt(e_new / e) - (kMassNo - 1.0) * sqrt(e / e_new));
-    const double got = scatter_cosine<false>(e, e_new);
+    double root_ratio, inv_root_ratio;
+    const double got = scatter_cosine<false>(e, e_new, root_ratio, inv_root_ratio);
     bad += (__double_as_longlong(got) != __double_as_longlong(want));
+    /* the speed after the scatter, from the speed before it (omp3/neutral.c:297) */
+    const double speed = sqrt((2.0 * e * kEvToJ) / kParticleMass);
+    const double want_speed = sqrt((2.0 * e_new * kEvToJ) / kParticleMass);
+    const double got_speed = speed_after_scatter(e_new, speed, refined_reciprocal(speed), root_ratio, inv_root_ratio);
+    bad_speed += (__double_as_longlong(got_speed) != __double_as_longlong(want_speed));
   }
   atomicAdd(&out[0], bad);
+  atomicAdd(&out[1], bad_speed);
 }
 
 int main() {
@@ -33,6 +40,6 @@ int main() {
   hipLaunchKernelGGL(probe, dim3(blocks), dim3(256), 0, 0, d, iters, 2026ull);
   CHECK(hipDeviceSynchronize());
   unsigned long long h[8]; CHECK(hipMemcpy(h, d, 64, hipMemcpyDeviceToHost));
-  printf("scatters %.3e: %llu cosines differ from the IEEE evaluation\n", (double)blocks * 256 * iters, h[0]);
+  printf("scatters %.3e: %llu cosines and %llu speeds differ from the IEEE evaluation\n", (double)blocks * 256 * iters, h[0], h[1]);
   return 0;
 }
