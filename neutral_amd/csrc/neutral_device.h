@@ -113,6 +113,14 @@ __device__ __forceinline__ void generate_random_numbers(uint64_t pkey,
   rn1 = u64_to_unit(r1);
 }
 
+/* Is the sample u64_to_unit(r) below one half?  Asked of the integer: float(r) rounds r to a
+ * multiple of 2^10 up there, times 2^-64 plus 2^-65 is rounded once more, and the result is below
+ * 0.5 exactly for r < 2^63 - 512 (2^63 - 512 itself is a tie that rounds to even, 2^63, and
+ * 0.5 + 2^-65 rounds to 0.5) -- tests/test_oracle_pins.py walks the boundary and two million
+ * random r.  One 64-bit comparison for two conversions, two fused multiply-adds and the
+ * comparison: what an absorb-or-scatter decision at probability one half costs. */
+__device__ __forceinline__ bool sample_below_half(uint64_t r) { return r < 0x7FFFFFFFFFFFFE00ull; }
+
 /* element `index` (>= 0) of an f64 array through an unsigned 32-bit byte offset: the
  * load then takes its base from scalar registers and one shifted vector register,
  * where a signed 64-bit index costs a sign extension and a 64-bit add per access

@@ -1087,10 +1087,20 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   /* identical tables: macro_s and macro_a are the same bits (macroscopic_from_micro) */
   const double p_absorb = kSameTables ? half_or_quotient<kChecked>(h.macro_a, h.macro_s + h.macro_a)
                                       : h.macro_a / (h.macro_s + h.macro_a);
-  double rc0, rc1;
-  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
-
-  const bool absorbed = (rc0 < p_absorb);
+  double rc1;
+  bool absorbed;
+  if (kSameTables && !kChecked) {
+    /* p_absorb is exactly one half: the first sample is compared as the integer it is made of
+     * (sample_below_half: the same answer) and never converted */
+    uint64_t r0, r1;
+    threefry2x64_20(h.counter++, a.pid_base + (uint64_t)h.id, a.master_key, r0, r1);
+    absorbed = sample_below_half(r0);
+    rc1 = u64_to_unit(r1);
+  } else {
+    double rc0;
+    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
+    absorbed = (rc0 < p_absorb);
+  }
   /* absorption: the weight drops; below 1 eV the history ends here.  The short pieces
    * are selects: a divergent region costs the collision stage more in exec-mask
    * bookkeeping and a branch than the few vector instructions it would skip. */

@@ -65,6 +65,28 @@ def test_random_numbers_unit_interval():
     assert 0.45 < flat.mean() < 0.55
 
 
+def test_a_sample_is_below_one_half_exactly_when_its_integer_is_below_2_63_minus_512():
+    """The HIP path decides absorb-or-scatter at probability one half (identical tables) on the
+    64-bit integer the first sample is made of (neutral_device.h: sample_below_half) instead of on
+    the double omp3/neutral.c:646-651 make of it: float(r) rounds to a multiple of 2^10 up there,
+    * 2^-64 + 2^-65 is rounded once more, and the result is < 0.5 exactly for r < 2^63 - 512.
+    The boundary walked integer by integer, the ends, and two million random integers."""
+    threshold = 0x7FFFFFFFFFFFFE00
+    def below_half(r):
+        return (float(r) * 2.0 ** -64 + 2.0 ** -65) < 0.5     # the reference's arithmetic, in IEEE doubles
+    for r in list(range(2 ** 63 - 5000, 2 ** 63 + 5000)) + [0, 1, 2 ** 63, 2 ** 64 - 1]:
+        assert below_half(r) == (r < threshold), hex(r)
+    rng = np.random.default_rng(7)
+    r = rng.integers(0, 2 ** 64, 2_000_000, dtype=np.uint64)
+    as_double = r.astype(np.float64) * 2.0 ** -64 + 2.0 ** -65   # (numpy converts round-to-nearest too)
+    assert np.array_equal(as_double < 0.5, r < np.uint64(threshold))
+    # the same through the oracle's own conversion
+    for c in range(2000):
+        a, _ = ob.threefry(c, 0, 99, 1)
+        r0, _ = ob.generate_random_numbers(99, 1, c)
+        assert (r0 < 0.5) == (a < threshold)
+
+
 def test_recorded_not_reproducible_here__cs_lookup_values(pins, cs):
     table = ob.CsTable(*cs)
     for e in pins["cs_lookup"]:
