@@ -113,6 +113,15 @@ __device__ __forceinline__ void generate_random_numbers(uint64_t pkey,
   rn1 = u64_to_unit(r1);
 }
 
+/* 2^64 times the sample: (double)r + 0.5, rounded once -- u64_to_unit(r) is this scaled by a
+ * power of two, which commutes with the rounding.  What a sample's consumers that can take the
+ * power of two along use instead of the sample (the logarithm: log_core(.., -64); the
+ * scattering cosine of the centre of mass: 1 - 2^-63 x): an addition of an inline constant where the
+ * sample costs a multiply-add whose addend, 2^-65, is moved into a register pair first. */
+__device__ __forceinline__ double u64_plus_half(uint64_t r) {
+  return __builtin_fma((double)(uint32_t)(r >> 32), 4294967296.0, (double)(uint32_t)r) + 0.5;
+}
+
 /* Is the sample u64_to_unit(r) below one half?  Asked of the integer: float(r) rounds r to a
  * multiple of 2^10 up there, times 2^-64 plus 2^-65 is rounded once more, and the result is below
  * 0.5 exactly for r < 2^63 - 512 (2^63 - 512 itself is a tie that rounds to even, 2^63, and

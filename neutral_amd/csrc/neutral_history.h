@@ -1087,19 +1087,21 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   /* identical tables: macro_s and macro_a are the same bits (macroscopic_from_micro) */
   const double p_absorb = kSameTables ? half_or_quotient<kChecked>(h.macro_a, h.macro_s + h.macro_a)
                                       : h.macro_a / (h.macro_s + h.macro_a);
-  double rc1;
+  double mu_cm; /* (:254: 1 - 2 x the second sample) */
   bool absorbed;
   if (kSameTables && !kChecked) {
     /* p_absorb is exactly one half: the first sample is compared as the integer it is made of
-     * (sample_below_half: the same answer) and never converted */
+     * (sample_below_half: the same answer) and never converted; the second enters the cosine
+     * as 2^64 times itself (u64_plus_half: 1 - 2 (2^-64 x) is one fused operation either way) */
     uint64_t r0, r1;
     threefry2x64_20(h.counter++, a.pid_base + (uint64_t)h.id, a.master_key, r0, r1);
     absorbed = sample_below_half(r0);
-    rc1 = u64_to_unit(r1);
+    mu_cm = __builtin_fma(u64_plus_half(r1), -0x1p-63, 1.0);
   } else {
-    double rc0;
+    double rc0, rc1;
     generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rc0, rc1);
     absorbed = (rc0 < p_absorb);
+    mu_cm = 1.0 - 2.0 * rc1;
   }
   /* absorption: the weight drops; below 1 eV the history ends here.  The short pieces
    * are selects: a divergent region costs the collision stage more in exec-mask
@@ -1120,7 +1122,6 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
   /* The energy after the collision is known before the scattering angle is: the
    * table search for it (:281-286) starts here, and its first probe is in flight
    * while the scattered lanes work out their direction (:254-272). */
-  const double mu_cm = 1.0 - 2.0 * rc1;
   const double e_scattered = quotient_of_physical_by_constant<ByMassNoPlusOneSquared, kChecked>(
       h.energy * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared,
       1.0 / kMassNoPlusOneSquared);
@@ -1152,9 +1153,17 @@ __device__ __forceinline__ bool collide(History& h, const SolveArgs& a,
 
   /* the draw for the next free flight (:293-295) needs nothing from the tables: it
    * and its logarithm are worked out while the search is still in flight */
-  double rn0, rn1;
-  generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
-  const double minus_log_rn0 = -log_of_drawn_sample<kChecked>(rn0);
+  double minus_log_rn0;
+  if (kChecked) {
+    double rn0, rn1;
+    generate_random_numbers(a.pid_base + (uint64_t)h.id, a.master_key, h.counter++, rn0, rn1);
+    minus_log_rn0 = -log_of_sample(rn0);
+  } else {
+    /* (log(2^-64 x) = log_core(x, -64): the same mantissa, the power of two in the exponent) */
+    uint64_t r0, r1;
+    threefry2x64_20(h.counter++, a.pid_base + (uint64_t)h.id, a.master_key, r0, r1);
+    minus_log_rn0 = -log_core(u64_plus_half(r0), -64);
+  }
 
   lookup_cs_finish<kSameTables, kChecked>(a, search, h.energy, h.micro_s, h.micro_a);
   if (kChecked) {
