@@ -434,7 +434,7 @@ __device__ __forceinline__ void refresh_direction(History& h) {
  * least 2^-150, so omega * speed lies in [2^-187, 2^101] for every speed of the proven range --
  * the division's wrapping (v_div_scale / v_div_fmas / v_div_fixup) is the identity and the
  * refined reciprocal with its one correction delivers the bits of 1.0 / (omega * speed)
- * (neutral_device.h: quotient_by_reciprocal; 14 operations for 24).  Asked of the wave: a
+ * (neutral_device.h: quotient_by_reciprocal; 11 operations and one seed for 24 and two).  Asked of the wave: a
  * cosine of exactly zero, a NaN (a scattering cosine that rounding pushed past 1: :266) or
  * anything else outside sends every lane through the wrapped divisions above. */
 __device__ __forceinline__ void refresh_direction_plain_or_wrapped(History& h) {
@@ -442,10 +442,17 @@ __device__ __forceinline__ void refresh_direction_plain_or_wrapped(History& h) {
   const unsigned hi = (unsigned)__double2hiint(both) & 0x7FFFFFFFu;
   const bool plain = (hi - ((1023u - 150u) << 20)) < (200u << 20); /* 2^-150 <= |both| < 2^50 */
   if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+    /* ... and both off ONE quarter-rate seed: the refined reciprocal of ux uy (within 2^-48.8)
+     * times uy is 1 / ux to 2^-48, and the residual correction with that same value as the
+     * reciprocal leaves 2^-96 (tools/micro/scatter_cosine.hip counts the pairs that differ from
+     * the two divisions) */
     const double ux = h.omega_x * h.speed;
     const double uy = h.omega_y * h.speed;
-    h.u_x_inv = quotient_by_reciprocal(1.0, ux, refined_reciprocal(ux));
-    h.u_y_inv = quotient_by_reciprocal(1.0, uy, refined_reciprocal(uy));
+    const double r_both = refined_reciprocal(ux * uy);
+    const double qx = r_both * uy;
+    const double qy = r_both * ux;
+    h.u_x_inv = __builtin_fma(__builtin_fma(-ux, qx, 1.0), qx, qx);
+    h.u_y_inv = __builtin_fma(__builtin_fma(-uy, qy, 1.0), qy, qy);
   } else {
     asm volatile("" ::: "memory"); /* keep the rare path a branch, not a select */
     refresh_direction(h);

@@ -13,7 +13,7 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51a
 
 __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters, uint64_t seed) {
   const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long bad = 0, bad_speed = 0;
+  unsigned long long bad = 0, bad_speed = 0, bad_dir = 0;
   for (int i = 0; i < iters; ++i) {
     const uint64_t h = mix(seed + tid * 0x9E3779B97F4A7C15ull + (uint64_t)i);
     const double u = u64_to_unit(h), v = u64_to_unit(mix(h + 1));
@@ -29,9 +29,20 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters,
     const double want_speed = sqrt((2.0 * e_new * kEvToJ) / kParticleMass);
     const double got_speed = speed_after_scatter(e_new, speed, refined_reciprocal(speed), root_ratio, inv_root_ratio);
     bad_speed += (__double_as_longlong(got_speed) != __double_as_longlong(want_speed));
+    /* the direction's two reciprocals 1 / (omega speed) off one seed (refresh_direction_plain_or_wrapped) */
+    const double ang = 6.283185307179586 * u64_to_unit(mix(h + 2));
+    double ox = cos(ang), oy = sin(ang);
+    if ((h & 1023) == 0) ox *= exp2(-100.0 * u); /* (some nearly axis-parallel) */
+    const double ux = ox * want_speed, uy = oy * want_speed;
+    const double r_both = refined_reciprocal(ux * uy);
+    const double qx = r_both * uy, qy = r_both * ux;
+    const double gx = __builtin_fma(__builtin_fma(-ux, qx, 1.0), qx, qx);
+    const double gy = __builtin_fma(__builtin_fma(-uy, qy, 1.0), qy, qy);
+    bad_dir += (__double_as_longlong(gx) != __double_as_longlong(1.0 / ux)) + (__double_as_longlong(gy) != __double_as_longlong(1.0 / uy));
   }
   atomicAdd(&out[0], bad);
   atomicAdd(&out[1], bad_speed);
+  atomicAdd(&out[2], bad_dir);
 }
 
 int main() {
@@ -40,6 +51,6 @@ int main() {
   hipLaunchKernelGGL(probe, dim3(blocks), dim3(256), 0, 0, d, iters, 2026ull);
   CHECK(hipDeviceSynchronize());
   unsigned long long h[8]; CHECK(hipMemcpy(h, d, 64, hipMemcpyDeviceToHost));
-  printf("scatters %.3e: %llu cosines and %llu speeds differ from the IEEE evaluation\n", (double)blocks * 256 * iters, h[0], h[1]);
+  printf("scatters %.3e: %llu cosines, %llu speeds and %llu direction reciprocals differ from the IEEE evaluation\n", (double)blocks * 256 * iters, h[0], h[1], h[2]);
   return 0;
 }
