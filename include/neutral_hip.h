@@ -442,6 +442,13 @@ void neutral_hip_probe_division(const double* in2, double* out2, int* plain, int
  *              divides, x / (MASS_NO+1)^2 the kernels' way (:252), as the compiler
  *              divides} */
 void neutral_hip_probe_log(const double* x, double* out8, int n);
+/*   scatter:   in4 = n rows {energy, the centre-of-mass cosine mu, omega_x, omega_y}; out10 = n rows
+ *              {the energy after the scatter (omp3/neutral.c:257-259), the laboratory cosine
+ *              (:263-265) the fast kernels' way and with IEEE divisions and roots, the speed
+ *              after the scatter (:297) from the speed before it and as sqrt(2 E' eV / m),
+ *              1 / (omega_x speed) and 1 / (omega_y speed) (:435-436) off one reciprocal and as
+ *              two divisions, 0}: what the fast arithmetic policy seeds from its neighbours */
+void neutral_hip_probe_scatter(const double* in4, double* out10, int n);
 /* Library/ABI version, bumped on any signature change. */
 int neutral_hip_abi_version(void);
 

@@ -36,7 +36,7 @@ int get_key_value_parameter(const char* specifier, const char* filename, char* k
 int within_tolerance(const double expected, const double result, const double tolerance);
 }
 
-#define NEUTRAL_ABI_VERSION 9 /* 9: NeutralHipStepStats grew weighted_waves, stream_clock_ghz, collide_clock_ghz; 8: NeutralHipStepStats grew steals_refused, stream_hops, stream_overflows; 7: NeutralHipStepStats grew steals; 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
+#define NEUTRAL_ABI_VERSION 10 /* 10: probe_scatter; 9: NeutralHipStepStats grew weighted_waves, stream_clock_ghz, collide_clock_ghz; 8: NeutralHipStepStats grew steals_refused, stream_hops, stream_overflows; 7: NeutralHipStepStats grew steals; 6: set_arithmetic, NeutralHipStepStats grew checked_arithmetic, attempts, host_collectives, exchange_ranks; 5: NeutralHipStepStats grew export_ms; 2: probe_division, NeutralHipStepStats grew requeued + collide_passes; 3: probe_log;
                                  4: invalidate_particles, NeutralHipStepStats grew host_syncs, stream_passes_enqueued, tile_cells */
 #define NEUTRAL_MAX_KEYS 40
 #define NEUTRAL_MAX_STR_LEN 1024

@@ -847,6 +847,14 @@ void neutral_hip_probe_log(const double* x, double* out8, int n) {
   HIP_CHECK(hipFree(d_in));
 }
 
+void neutral_hip_probe_scatter(const double* in4, double* out10, int n) {
+  double* d_in = stage_in(in4, (size_t)4 * n);
+  double* d_out = stage_in((const double*)nullptr, (size_t)10 * n);
+  HIP_CHECK(neutral::launch_probe_scatter(d_in, d_out, n, g.stream));
+  stage_out(out10, d_out, (size_t)10 * n);
+  HIP_CHECK(hipFree(d_in));
+}
+
 void neutral_hip_synchronize(void) { HIP_CHECK(hipStreamSynchronize(g.stream)); }
 int neutral_hip_abi_version(void) { return NEUTRAL_ABI_VERSION; }
 

@@ -474,6 +474,7 @@ hipError_t launch_probe_facet(const double* in, double* dist, int* x_facet, int 
 hipError_t launch_probe_division(const double* in, double* out, int* plain, int n,
                                  hipStream_t stream);
 hipError_t launch_probe_log(const double* in, double* out, int n, hipStream_t stream);
+hipError_t launch_probe_scatter(const double* in, double* out, int n, hipStream_t stream);
 
 }  // namespace neutral
 #endif

@@ -1285,6 +1285,40 @@ __global__ __launch_bounds__(kBlock) void probe_log_kernel(const double* in, dou
   }
 }
 
+__global__ __launch_bounds__(kBlock) void probe_scatter_kernel(const double* in, double* out, int n) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    /* in: {energy, mu_cm, omega_x, omega_y} per row */
+    const double e = in[4 * i], mu_cm = in[4 * i + 1];
+    const double e_new = quotient_of_physical_by_constant<ByMassNoPlusOneSquared, false>(
+        e * (kMassNo * kMassNo + 2.0 * kMassNo * mu_cm + 1.0), kMassNoPlusOneSquared, 1.0 / kMassNoPlusOneSquared);
+    double root_ratio, inv_root_ratio, unused0, unused1;
+    const double speed = speed_of<true>(e);
+    History h;
+    h.omega_x = in[4 * i + 2];
+    h.omega_y = in[4 * i + 3];
+    h.speed = speed_of<true>(e_new);
+    double* const o = out + 10 * i;
+    o[0] = e_new;
+    o[1] = scatter_cosine<false>(e, e_new, root_ratio, inv_root_ratio);
+    o[2] = scatter_cosine<true>(e, e_new, unused0, unused1);
+    o[3] = speed_after_scatter(e_new, speed, refined_reciprocal(speed), root_ratio, inv_root_ratio);
+    o[4] = h.speed;
+    refresh_direction_plain_or_wrapped(h);
+    o[5] = h.u_x_inv;
+    o[6] = h.u_y_inv;
+    refresh_direction(h);
+    o[7] = h.u_x_inv;
+    o[8] = h.u_y_inv;
+    o[9] = 0.0;
+  }
+}
+
+hipError_t launch_probe_scatter(const double* in, double* out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_scatter_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_probe_log(const double* in, double* out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(probe_log_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                      in, out, n);

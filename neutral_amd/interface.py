@@ -103,7 +103,7 @@ ABI_SYMBOLS = (
     "neutral_hip_memcpy_d2h", "neutral_hip_memcpy_h2d", "neutral_hip_memset",
     "neutral_hip_synchronize", "neutral_hip_abi_version",
     "neutral_hip_probe_threefry", "neutral_hip_probe_cs_lookup",
-    "neutral_hip_probe_distance_to_facet", "neutral_hip_probe_division",
+    "neutral_hip_probe_distance_to_facet", "neutral_hip_probe_division", "neutral_hip_probe_scatter",
     "neutral_hip_probe_log",
 )
 
@@ -175,6 +175,7 @@ _lib.neutral_hip_probe_threefry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, 
 _lib.neutral_hip_probe_cs_lookup.argtypes = [C.POINTER(CrossSection), C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int]
 _lib.neutral_hip_probe_division.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+_lib.neutral_hip_probe_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 _lib.neutral_hip_probe_distance_to_facet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int]
@@ -319,6 +320,17 @@ def probe_division(rows: np.ndarray):
     _lib.neutral_hip_probe_division(a.ctypes.data, out.ctypes.data, plain.ctypes.data,
                                     a.shape[0])
     return out[:, 0], out[:, 1], plain.astype(bool)
+
+
+def probe_scatter(rows: np.ndarray):
+    """rows {energy, mu_cm, omega_x, omega_y} -> dict of the scatter's kinematics the fast kernels' way and
+    with IEEE divisions and roots (include/neutral_hip.h: neutral_hip_probe_scatter)"""
+    a = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 4)
+    out = np.zeros((a.shape[0], 10), dtype=np.float64)
+    _lib.neutral_hip_probe_scatter(a.ctypes.data, out.ctypes.data, a.shape[0])
+    names = ("e_new", "cos_fast", "cos_ieee", "speed_fast", "speed_ieee", "u_x_inv_fast", "u_y_inv_fast",
+             "u_x_inv_ieee", "u_y_inv_ieee")
+    return {k: out[:, j] for j, k in enumerate(names)}
 
 
 def probe_log(x: np.ndarray):

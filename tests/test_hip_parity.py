@@ -192,6 +192,42 @@ def test_quotient_through_kept_reciprocal_is_the_ieee_quotient(iface):
           % (int((step != 0).sum()), int(adversarial.sum()), int(ordinary.sum())))
 
 
+def test_a_scatter_seeded_from_its_neighbours_gives_the_ieee_results(iface):
+    """The fast arithmetic policy works out a scatter's second quotient and second root from the
+    first, the speed after it from the speed before it, and the direction's two reciprocals off one
+    (neutral_device.h: scatter_cosine, speed_after_scatter; neutral_history.h:
+    refresh_direction_plain_or_wrapped) -- one residual correction each after a seed that is
+    good to 2^-46 and better.  Two million random scatters over the tables' energy range, with
+    nearly axis-parallel directions among them: the bits of the evaluation with IEEE divisions
+    and roots (the checked policy's), which are what numpy computes from omp3/neutral.c:263-265,
+    :297 and :435-436 (the speed and the reciprocals bit for bit).  (tools/micro/scatter_cosine.hip counts 8.6e9 on the device: none differ.)"""
+    rng = np.random.default_rng(2026)
+    n = 2_000_000
+    e = 1.0e-2 * 2.0 ** (rng.random(n) * 33.2)                 # 1e-2 ... 1e8 eV
+    mu = 1.0 - 2.0 * rng.random(n)
+    ang = 2.0 * np.pi * rng.random(n)
+    ox, oy = np.cos(ang), np.sin(ang)
+    thin = rng.integers(0, 64, n) == 0
+    ox = np.where(thin, ox * 2.0 ** -rng.integers(1, 140, n), ox)     # some nearly axis-parallel
+    got = iface.probe_scatter(np.stack([e, mu, ox, oy], axis=1))
+    same = lambda a, b: np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    e_new = got["e_new"]
+    assert np.all((e_new > 0.95 * e) & (e_new < 1.05 * e))
+    mass_no = 100.0
+    with np.errstate(all="ignore"):
+        cos_np = 0.5 * ((mass_no + 1.0) * np.sqrt(e_new / e) - (mass_no - 1.0) * np.sqrt(e / e_new))
+        speed_np = np.sqrt((2.0 * e_new * 1.60217646e-19) / 1.674927471213e-27)
+        ux_np, uy_np = 1.0 / (ox * speed_np), 1.0 / (oy * speed_np)
+    # (the cosine's last combination a * s1 - b * s2 may be contracted into a fused multiply-add on the
+    #  device, as in the reference's own -O3 build: numpy's two roundings are an ulp or two away)
+    assert np.max(np.abs(got["cos_ieee"] - cos_np)) < 4.0e-14
+    assert same(got["speed_ieee"], speed_np)
+    assert same(got["u_x_inv_ieee"], ux_np) and same(got["u_y_inv_ieee"], uy_np)
+    assert same(got["cos_fast"], got["cos_ieee"])
+    assert same(got["speed_fast"], got["speed_ieee"])
+    assert same(got["u_x_inv_fast"], got["u_x_inv_ieee"]) and same(got["u_y_inv_fast"], got["u_y_inv_ieee"])
+
+
 def test_log_of_a_sample_is_faithful(iface):
     """The history kernels take -log of a (0,1] sample with their own evaluation
     (neutral_device.h: log_of_sample) instead of the device library's.  Measured here
