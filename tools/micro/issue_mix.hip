@@ -79,6 +79,9 @@ constexpr int kUnroll = 8;
 /* exec narrowed and restored around one vector instruction */
 #define EXEC_TOGGLE asm volatile("s_and_saveexec_b64 %0, %1\n v_add_u32_e32 %2, 1, %2\n s_mov_b64 exec, %0" : "=s"(mk), "+s"(s1), "+v"(x) : : "scc");
 #define LDS_ADD asm volatile("ds_add_f64 %0, %1" : : "v"(lds_addr), "v"(a7) : "memory");
+/* a quarter-rate instruction whose result nothing in the block waits for: does it issue beside the others? */
+#define RCP asm volatile("v_rcp_f64 %0, %1" : "=v"(rc) : "v"(a7));
+#define RSQ asm volatile("v_rsq_f64 %0, %1" : "=v"(rc) : "v"(a7));
 #define SNOP asm volatile("s_nop 0");
 #define WAITCNT asm volatile("s_waitcnt lgkmcnt(15)");
 
@@ -92,16 +95,17 @@ constexpr int kUnroll = 8;
     unsigned long long s0 = k1 | 3ull, s1 = k1 | 5ull, mk = 0;                                      \
     unsigned s2 = k2;                                                                               \
     unsigned x = threadIdx.x, y = threadIdx.x * 3u;                                                 \
+    double rc = 0.0;                                                                                \
     /* every lane its own cell, consecutive: no bank conflict, no address conflict */               \
     const unsigned lds_addr = threadIdx.x * 8u;                                                     \
     lds[threadIdx.x] = 0.0;                                                                         \
-    (void)lds_addr; (void)s2; (void)mk; (void)x; (void)y;                                           \
+    (void)lds_addr; (void)s2; (void)mk; (void)x; (void)y; (void)rc;                                 \
     _Pragma("unroll 1") for (int i = 0; i < kIters; ++i) {                                          \
       _Pragma("unroll") for (int j = 0; j < kUnroll; ++j) { BODY }                                  \
     }                                                                                               \
     out[blockIdx.x * blockDim.x + threadIdx.x] =                                                    \
         a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(s0 & 1) + (double)x + (double)(mk & 1) +   \
-        lds[threadIdx.x];                                                                           \
+        lds[threadIdx.x] + rc;                                                                      \
   }
 
 KERNEL(k_valu, VALU8)
@@ -125,6 +129,10 @@ KERNEL(k_exec_toggle4, VALU8_WITH_EVERY_OTHER(EXEC_TOGGLE))
 KERNEL(k_lds1, VALU8_WITH_ONE(LDS_ADD))
 KERNEL(k_lds4, VALU8_WITH_EVERY_OTHER(LDS_ADD))
 KERNEL(k_snop8, VALU8_WITH(SNOP))
+KERNEL(k_rcp1, VALU8_WITH_ONE(RCP))
+KERNEL(k_rcp4, VALU8_WITH_EVERY_OTHER(RCP))
+KERNEL(k_rsq1, VALU8_WITH_ONE(RSQ))
+KERNEL(k_rcp_only, RCP RCP RCP RCP RCP RCP RCP RCP)
 KERNEL(k_facet_like, VALU8_WITH_EVERY_OTHER(SALU) BR_UNTAKEN CMP_SALU_SELECT)
 
 typedef void (*kernel_t)(double*, double, unsigned long long, unsigned);
@@ -163,6 +171,10 @@ int main() {
       {"+1 ds_add_f64", k_lds1, 0},
       {"+4 ds_add_f64", k_lds4, 0},
       {"+8 s_nop 0", k_snop8, 0},
+      {"+1 v_rcp_f64 (result unused by the block)", k_rcp1, 1},
+      {"+4 v_rcp_f64", k_rcp4, 4},
+      {"+1 v_rsq_f64", k_rsq1, 1},
+      {"8 v_rcp_f64 alone (no v_mul_f64)", k_rcp_only, 8},
       {"+4 s_and, 1 branch not taken, 1 cmp-s_and-select", k_facet_like, 2},
   };
   printf("%d CUs; SIMD cycles per block (8 v_mul_f64 + what the row names; 32 = the vector unit alone; %.1f GHz assumed)\n", cus, ghz);
