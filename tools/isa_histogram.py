@@ -19,7 +19,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "neutral_amd", "build")
+BUILD = os.environ.get("NEUTRAL_ISA_BUILD") or os.path.join(ROOT, "neutral_amd", "build")  # (another directory: flag sweeps)
 
 TARGETS = {
     "collide": ("neutral_kernels-hip-amdgcn-amd-amdhsa-gfx950.s",
